@@ -1,0 +1,113 @@
+"""Seeded input generators shared by oracle/make_goldens.py and the tests.
+
+The golden .npz files store OUTPUTS of the reference; inputs are regenerated
+here from fixed seeds (legacy ``np.random.seed`` for the reference's unit-test
+inputs, PCG64 otherwise), except the reference's own real-data fixture
+(sst/prcp) which is stored in ``tests/golden/reference_fixtures.npz``.
+"""
+import os
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _unit_fields():
+    # reference tests/unit/test_array.py:8-14
+    np.random.seed(7)
+    left = np.random.rand(500, 20, 15)
+    np.random.seed(8)
+    right = np.random.rand(500, 15, 10)
+    return left, right
+
+
+def _signal_field(rng, T, N, k, amp0=10.0, decay=0.8, noise=0.5, pcs=None):
+    """low-rank signal with geometric amplitudes (well separated modes) + noise."""
+    if pcs is None:
+        pcs = rng.standard_normal((T, k))
+    amp = amp0 * decay ** np.arange(k)
+    pat = np.zeros((k, N))
+    w = max(N // k, 1)
+    for j in range(k):
+        pat[j, j * w:(j + 1) * w] = np.hanning(w + 2)[1:-1]
+    pat = pat + 0.2 * rng.standard_normal((k, k)) @ pat
+    return (pcs * amp) @ pat + noise * rng.standard_normal((T, N)), pcs
+
+
+def _wide(dtype=np.float64):
+    rng = np.random.default_rng(11)
+    T = 64
+    t = np.arange(T)[:, None]
+    f = np.linspace(0.03, 0.3, 8)[None, :]
+    pcs = np.cos(2 * np.pi * f * t + rng.uniform(0, 6.28, (1, 8)))
+    a, _ = _signal_field(rng, T, 300, 8, pcs=pcs)
+    b, _ = _signal_field(rng, T, 200, 8, pcs=pcs)
+    return a.astype(dtype), b.astype(dtype)
+
+
+def _small():
+    rng = np.random.default_rng(21)
+    T = 40
+    pcs = rng.standard_normal((T, 4))
+    a, _ = _signal_field(rng, T, 24, 4, pcs=pcs, noise=0.3)
+    b, _ = _signal_field(rng, T, 18, 4, pcs=pcs, noise=0.3)
+    return a.reshape(T, 4, 6), b.reshape(T, 3, 6)
+
+
+def _mixed():
+    # one field wider than T, the other narrower: exercises both Gram orientations
+    rng = np.random.default_rng(31)
+    T = 48
+    pcs = rng.standard_normal((T, 5))
+    a, _ = _signal_field(rng, T, 120, 5, pcs=pcs)
+    b, _ = _signal_field(rng, T, 30, 5, pcs=pcs)
+    return a, b
+
+
+def _loadings(tag):
+    spec = {"r4": (300, 4, False, 41), "r10": (300, 10, False, 42), "r10p4": (300, 10, False, 43),
+            "c4": (300, 4, True, 44), "c10p4": (300, 10, True, 45), "c10p2": (300, 10, True, 46)}
+    n, p, cplx, seed = spec[tag]
+    rng = np.random.default_rng(seed)
+    # "simple structure": each column loads mostly on its own row band, then mixed by
+    # a random orthogonal/unitary matrix so Varimax has something to undo.
+    L = 0.15 * rng.standard_normal((n, p))
+    w = n // p
+    for j in range(p):
+        L[j * w:(j + 1) * w, j] += np.hanning(w) * (3.0 - 0.15 * j)
+    if cplx:
+        L = L * np.exp(1j * rng.uniform(0, 2 * np.pi, (n, 1)) * 0.3) + 0.05j * rng.standard_normal((n, p))
+        M = rng.standard_normal((p, p)) + 1j * rng.standard_normal((p, p))
+    else:
+        M = rng.standard_normal((p, p))
+    Q, _ = np.linalg.qr(M)
+    return L @ Q
+
+
+def make_input(name):
+    """Returns a tuple of 1 or 2 arrays (time first)."""
+    if name == "unit_left":
+        return (_unit_fields()[0],)
+    if name == "unit_both":
+        return _unit_fields()
+    if name == "wide_left":
+        return (_wide()[0],)
+    if name == "wide_both":
+        return _wide()
+    if name == "wide_both_f32":
+        return _wide(np.float32)
+    if name == "small_both":
+        return _small()
+    if name == "mixed_both":
+        return _mixed()
+    if name == "sst_prcp":
+        fx = np.load(os.path.join(GOLDEN_DIR, "reference_fixtures.npz"))
+        return fx["sst"], fx["prcp"]
+    if name.startswith("loadings_"):
+        tag = name[len("loadings_"):]
+        if tag == "noconv":
+            # complex white noise: the reference needs 2760 iterations (> maxIter=1000)
+            rng = np.random.default_rng(1)
+            return (rng.standard_normal((1000, 20)) + 1j * rng.standard_normal((1000, 20)),)
+        return (_loadings(tag),)
+    raise KeyError(name)
