@@ -1,0 +1,123 @@
+/*
+ * xmca_hip.h - C ABI of the MI355X (gfx950) implementation of the xmca solve / rotate / rule_n path.
+ *
+ * The reference (nicrie/xmca v1.4.2) is pure Python: it has no FFI of its own.  The drop-in boundary is
+ * therefore the private numerical core of xmca.array.MCA, and every entry point below names the reference
+ * lines it replaces.  The host side (xmca_amd/array.py) binds these symbols through ctypes; INTEGRATION.md
+ * shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only.  Return value: 0 = ok, negative = error code below;
+ *     xmca_last_error() returns the message of the last failure on that handle.
+ *   - The caller owns every host buffer.  The library owns all device memory inside the opaque handle.
+ *   - One handle = one HIP device + one stream.  A handle is not thread-safe; use one per thread / rank.
+ *   - Matrices are row-major.  Complex data is interleaved (re, im) in host buffers.
+ *   - dtype: 0 = float32, 1 = float64 (of the real components).
+ */
+#ifndef XMCA_HIP_H
+#define XMCA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XMCA_OK 0
+#define XMCA_ERR_INVALID (-1)        /* bad argument                                   -> ValueError            */
+#define XMCA_ERR_HIP (-2)            /* HIP runtime failure                            -> RuntimeError          */
+#define XMCA_ERR_NOT_CONVERGED (-3)  /* Varimax hit max_iter (rotation.py:66-71)       -> RuntimeError          */
+#define XMCA_ERR_STATE (-4)          /* call order (e.g. vectors before solve)         -> RuntimeError          */
+#define XMCA_ERR_UNSUPPORTED (-5)    /* outside device limits (e.g. n_rot too large)   -> NotImplementedError   */
+#define XMCA_ERR_NUMERIC (-6)        /* NaN / singular matrix (array.py:575-578)       -> numpy LinAlgError     */
+
+#define XMCA_F32 0
+#define XMCA_F64 1
+#define XMCA_HOST 0
+#define XMCA_DEVICE 1
+
+typedef struct xmca_handle xmca_handle;
+
+/* library / device management ------------------------------------------------------------------------- */
+const char* xmca_version(void);
+int xmca_device_count(void);
+int xmca_create(int device, xmca_handle** out);
+void xmca_destroy(xmca_handle* h);
+const char* xmca_last_error(xmca_handle* h);
+
+/* Input of solve(): the centered, weighted, NaN-free T x N field of one side (0 = left, 1 = right), i.e.
+ * MCA._fields[key] as returned by MCA._get_X()                         (xmca/array.py:95, :117, :289-298).
+ *   re        real part, T*N elements of `dtype`
+ *   im        imaginary part (analytic signal computed by the host, array.py:455-470) or NULL
+ *   location  XMCA_HOST: copied to the device;  XMCA_DEVICE: device pointers, adopted without a copy
+ *             (they must stay valid until the next xmca_set_field / xmca_destroy). */
+int xmca_set_field(xmca_handle* h, int side, const void* re, const void* im, int64_t T, int64_t N, int dtype, int location);
+
+/* Hilbert complexify on the device: X_im = Ht * X_re for every field set so far.  Ht (T x T) is the imaginary
+ * part of the analytic-signal operator, imag(scipy.signal.hilbert(eye(T), axis=0)); it is circulant, so the
+ * caller passes only its first column `hilbert_col` (T float64, host): Ht[t][s] = hilbert_col[(t - s) mod T].
+ * Replaces scipy.signal.hilbert(field, axis=0) of array.py:464 for extend=False. */
+int xmca_complexify(xmca_handle* h, const double* hilbert_col);
+
+/* MCA.solve numerical core (xmca/array.py:549-584): per-field SVD, kernel, kernel SVD, back-projection.
+ *   n_fields  1 (EOF/PCA) or 2 (MCA)
+ *   n_vec     number of leading modes to back-project into grid space; -1 = all `rank` modes
+ *   rank_out  min(T, Nx, Ny)  (array.py:597) */
+int xmca_solve(xmca_handle* h, int n_fields, int64_t n_vec, int64_t* rank_out);
+
+/* MCA._singular_values (array.py:590): all `rank` singular values of A^H B / (T-1), descending, float64. */
+int xmca_get_singular_values(xmca_handle* h, double* out, int64_t n);
+
+/* MCA._V[key] (array.py:584), transposed: out[m * N + n] = V[n][m] for m < n_modes; complex interleaved when
+ * the model is complex.  dtype selects float32 / float64 components. */
+int xmca_get_vectors(xmca_handle* h, int side, void* out, int64_t n_modes, int dtype);
+int xmca_is_complex(xmca_handle* h);
+
+/* promax / varimax of xmca/tools/rotation.py:84-149, :15-78 on a host loading matrix L (N x p row-major,
+ * float64, interleaved complex when is_complex), as built by MCA.rotate (array.py:821-822).
+ *   n_left        rows belonging to the left field (array.py:818, :827-828)
+ *   varimax_only  1: stop after Varimax (tools.rotation.varimax), 0: full Promax (also for power = 1)
+ *   B_out         NULL or N x p rotated loadings
+ *   R_out/Phi_out p x p (interleaved complex when is_complex); norm_left/right: p column norms of the two
+ *                 row blocks of the rotated loadings (array.py:827-828); iters_out: Varimax iterations run.
+ * Returns XMCA_ERR_NOT_CONVERGED when max_iter iterations did not satisfy |d - d_old| / d < tol. */
+int xmca_rotate_loadings(xmca_handle* h, const double* L, int64_t N, int64_t n_left, int p, int is_complex, int power,
+                         double tol, int max_iter, int varimax_only, double* B_out, double* R_out, double* Phi_out,
+                         double* norm_left, double* norm_right, int* iters_out);
+
+/* MCA.rule_n surrogate loop (xmca/array.py:1753-1765) for runs [run_begin, run_end): N(0,1) surrogates
+ * (Philox4x32-10 keyed by seed, run, side) generated on the device, centered, optionally complexified
+ * (hilbert_col != NULL, see xmca_complexify), solved and, when `rotated`, rotated with (p, power, tol); each kept run contributes
+ * MCA._get_variance() (array.py:772-779): n_out = rank values (unrotated) or p values (rotated), descending.
+ *   spectra_out  (run_end - run_begin) x n_out float64;  kept_out[i] = 0 when run i was dropped because
+ *                Varimax did not converge (array.py:1762-1763).
+ * The final normalisation svals /= svals.sum(0) / ref.sum() (array.py:1767-1769) is left to the caller
+ * because it needs the runs of every rank. */
+int xmca_rule_n(xmca_handle* h, int64_t T, int64_t Nx, int64_t Ny, int n_fields, const double* hilbert_col, int rotated,
+                int p, int power, double tol, int64_t run_begin, int64_t run_end, uint64_t seed, int dtype,
+                double* spectra_out, int* kept_out, int64_t n_out);
+
+/* Surrogate generator on its own (tests): T*N standard normals of (seed, run, side) as float64 on the host. */
+int xmca_surrogate(xmca_handle* h, int64_t n, uint64_t seed, uint32_t run, uint32_t side, double* out);
+
+/* hipEvent stage timers of the calls since the last reset: names are written as a ';'-separated list. */
+int xmca_get_timings(xmca_handle* h, char* names, int names_len, double* ms, int max_n);
+int xmca_reset_timings(xmca_handle* h);
+
+/* Kernel-level entry points used by the parity tests and the roofline leg of bench.py ------------------- */
+/* C (M x N, float64, host) = alpha * op(A) op(B);  a_kfast: A(m,k) = A[m*lda + k] else A[k*lda + m];
+ * b_nfast: B(k,n) = B[k*ldb + n] else B[n*ldb + k];  dtype of A and B; upper_only/mirror as in gemm.h. */
+int xmca_gemm(xmca_handle* h, const void* A, int64_t lda, int a_kfast, const void* B, int64_t ldb, int b_nfast, double* C,
+              int M, int N, int K, int dtype, double alpha, int upper_only, int mirror, int splits);
+/* Hermitian eigendecomposition of an n x n host matrix (interleaved complex when is_complex):
+ * lam (n, descending) and Zh (n x n, row i = conj(u_i)); info[0] = sweeps, info[1] = tile, info[2] = slots. */
+int xmca_eigh(xmca_handle* h, const double* A, int n, int is_complex, double* lam, double* Zh, int* info);
+/* Time `reps` Gram products G = X X^T of the resident field `side` with hipEvents on the library's stream;
+ * avg_ms = mean duration of one product (all launches it needs), kernel_ms = mean duration of the MFMA
+ * kernel launches alone, flops = useful flops of one product, T (T+1) N. */
+int xmca_bench_gram(xmca_handle* h, int side, int reps, double* avg_ms, double* kernel_ms, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XMCA_HIP_H */

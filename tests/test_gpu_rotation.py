@@ -1,0 +1,74 @@
+"""Varimax / Promax on the device vs. golden vectors generated from the reference's
+xmca/tools/rotation.py (tests/golden/rotation_direct.npz).  Same input loadings -> no gauge freedom:
+R, Phi, B and the ITERATION COUNT must match (tolerance 1e-7 relative, written below)."""
+import os
+
+import numpy as np
+import pytest
+
+from golden_inputs import GOLDEN_DIR, make_input
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-7
+
+
+def _rel(a, b):
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(GOLDEN_DIR, "rotation_direct.npz"))
+
+
+@pytest.mark.parametrize("tag", ["r4", "r10", "r10p4", "c4", "c10p4", "c10p2"])
+def test_promax_matches_reference(hip, gold, tag):
+    A = make_input("loadings_" + tag)[0]
+    power = int(gold[tag + "_power"])
+    out = hip.rotate_loadings(A, n_left=A.shape[0], power=power, tol=1e-8, want_B=True)
+    assert out["n_iter"] == int(gold[tag + "_n_iter"])
+    assert _rel(out["R"], gold[tag + "_R"]) < TOL
+    assert _rel(out["Phi"], gold[tag + "_Phi"]) < TOL
+    assert _rel(out["B"], gold[tag + "_B"]) < TOL
+    # column norms of the rotated loadings (what MCA.rotate keeps, array.py:827)
+    assert _rel(out["norm_left"], np.linalg.norm(gold[tag + "_B"], axis=0)) < TOL
+
+
+@pytest.mark.parametrize("tag", ["r4", "r10", "c4"])
+def test_varimax_matches_reference(hip, gold, tag):
+    A = make_input("loadings_" + tag)[0]
+    out = hip.rotate_loadings(A, n_left=A.shape[0], varimax_only=True, want_B=True)
+    assert _rel(out["R"], gold[tag + "_Rv"]) < TOL
+    assert _rel(out["B"], gold[tag + "_Bv"]) < TOL
+
+
+def test_split_norms(hip, gold):
+    A = make_input("loadings_r10p4")[0]
+    out = hip.rotate_loadings(A, n_left=120, power=4)
+    B = gold["r10p4_B"]
+    assert _rel(out["norm_left"], np.linalg.norm(B[:120], axis=0)) < TOL
+    assert _rel(out["norm_right"], np.linalg.norm(B[120:], axis=0)) < TOL
+
+
+def test_not_converged_raises_runtime_error(hip):
+    A = make_input("loadings_noconv")[0]
+    with pytest.raises(RuntimeError):
+        hip.rotate_loadings(A, n_left=A.shape[0], power=4)
+    assert hip.last_iters == 1000
+
+
+def test_argument_errors(hip):
+    A = make_input("loadings_r4")[0]
+    with pytest.raises(ValueError):
+        hip.rotate_loadings(A, n_left=10, power=0)
+    with pytest.raises(ValueError):
+        hip.rotate_loadings(A[:, :1], n_left=10)
+    with pytest.raises(NotImplementedError):
+        hip.rotate_loadings(np.ones((100, 65)) + np.arange(65), n_left=10)
+
+
+def test_zero_row_is_linalg_error(hip):
+    A = make_input("loadings_r4")[0].copy()
+    A[7] = 0.0           # Kaiser normalisation divides by the row norm -> NaN, as in the reference
+    with pytest.raises(np.linalg.LinAlgError):
+        hip.rotate_loadings(A, n_left=A.shape[0])

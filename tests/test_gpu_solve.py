@@ -1,0 +1,117 @@
+"""solve() numerical core on the device (through the C ABI) vs golden vectors produced by the reference
+(tests/golden/solve_cases.npz) and vs the numpy oracle on the same inputs.
+
+Tolerances (north_star): 1e-5 relative on singular values and on sign/phase-aligned loadings of the
+well-separated leading modes; float32 inputs are compared at the reference's own 1e-3 (test_integration_xarray.py:33-35)
+for the vectors and 2e-5 for the singular values (the reference itself runs sgesdd there).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import align_modes
+from golden_inputs import GOLDEN_DIR, make_input
+from oracle import ref_numpy as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(GOLDEN_DIR, "solve_cases.npz"))
+
+
+def device_solve(hip, fields, complexify, n_vec=-1):
+    prepared = [O.flatten_and_center(f)[0] for f in fields]
+    for s, f in enumerate(prepared):
+        hip.set_field(s, f)
+    if complexify:
+        hip.complexify(prepared[0].shape[0])
+    rank = hip.solve(len(prepared), n_vec)
+    sig = hip.singular_values(rank)
+    m = rank if n_vec < 0 else min(rank, n_vec)
+    V = [hip.vectors(s, m, f.shape[1], f.dtype).T for s, f in enumerate(prepared)]
+    return rank, sig, V
+
+
+CASES = ["unit_left", "unit_both", "wide_left", "wide_both", "mixed_both", "sst_prcp"]
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("name", CASES)
+def test_solve_matches_reference_goldens(hip, gold, name, cplx):
+    tag = name + ("_cplx" if cplx else "_std") + "__"
+    fields = make_input(name)
+    rank, sig, V = device_solve(hip, fields, cplx)
+    gs = gold[tag + "singular_values"].astype(np.float64)
+    assert rank == int(gold[tag + "rank"])
+    f32 = fields[0].dtype == np.float32
+    # singular values: every mode that is not numerically null (relative to the largest)
+    keep = gs > 1e-6 * gs[0]
+    assert np.max(np.abs(sig[keep] - gs[keep]) / gs[keep]) < (2e-5 if f32 else 1e-5)
+    assert abs(sig.sum() - float(gold[tag + "total_covariance"])) < (1e-4 if f32 else 1e-8) * gs.sum()
+    # leading vectors, phase aligned; only modes separated from their neighbours by > 2 % are pinned
+    for s, key in enumerate(["left", "right"][:len(fields)]):
+        gv = gold[tag + "V_" + key]
+        m = min(10, gv.shape[1])
+        gaps = np.minimum(np.abs(np.diff(gs[:m + 1], prepend=np.inf)), np.abs(np.diff(gs[:m + 1], append=0)))[:m] / gs[:m]
+        sel = np.where(gaps > 0.02)[0]
+        mine, _ = align_modes(V[s][:, :m], gv[:, :m])
+        err = np.max(np.abs(mine[:, sel] - gv[:, sel]), axis=0) / np.max(np.abs(gv[:, sel]), axis=0)
+        tol = 1e-3 if f32 else 1e-5 / np.minimum(gaps[sel], 1.0) * 0.1 + 1e-5
+        assert np.all(err < tol), (key, err, gaps[sel])
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_f32_fields(hip, gold, cplx):
+    tag = "wide_both_f32" + ("_cplx" if cplx else "_std") + "__"
+    fields = make_input("wide_both_f32")
+    rank, sig, V = device_solve(hip, fields, cplx)
+    gs = gold[tag + "singular_values"].astype(np.float64)
+    keep = gs > 1e-4 * gs[0]
+    assert np.max(np.abs(sig[keep] - gs[keep]) / gs[keep]) < 2e-5
+    assert V[0].dtype == (np.complex64 if cplx else np.float32)
+    gv = gold[tag + "V_left"]
+    mine, _ = align_modes(V[0][:, :5], gv[:, :5])
+    assert np.max(np.abs(mine - gv[:, :5])) < 1e-3
+
+
+def test_orthonormal_vectors_and_gauge(hip):
+    """properties the reference tests (test_orthogonality / test_correlation): V^H V = I and U_l^H U_r diagonal, real, positive."""
+    fields = make_input("wide_both")
+    rank, sig, V = device_solve(hip, fields, True)
+    X = [O.analytic_signal(O.flatten_and_center(f)[0]) for f in fields]
+    k = 12
+    for v in V:
+        assert np.max(np.abs(v[:, :k].conj().T @ v[:, :k] - np.eye(k))) < 1e-10
+    T = X[0].shape[0]
+    cov = (X[0] @ V[0][:, :k]).conj().T @ (X[1] @ V[1][:, :k]) / (T - 1)
+    assert np.max(np.abs(cov - np.diag(sig[:k]))) < 1e-9 * sig[0]
+
+
+def test_partial_backprojection(hip):
+    fields = make_input("wide_both")
+    rank, sig, V = device_solve(hip, fields, False, n_vec=6)
+    rank2, sig2, V2 = device_solve(hip, fields, False)
+    assert V[0].shape[1] == 6 and np.allclose(sig, sig2, rtol=1e-12)
+    mine, _ = align_modes(V[0], V2[0][:, :6])
+    assert np.max(np.abs(mine - V2[0][:, :6])) < 1e-10
+
+
+def test_errors(hip):
+    from xmca_amd import _hip
+    h = _hip.Handle(0)
+    with pytest.raises(RuntimeError):
+        h.solve(1)                                    # no field
+    h.set_field(0, np.zeros((10, 4)))
+    with pytest.raises(ValueError):
+        h.set_field(1, np.zeros((11, 4)))             # different T
+    with pytest.raises(RuntimeError):
+        h.singular_values(3)                          # before solve
+    bad = np.random.default_rng(0).standard_normal((12, 30))
+    bad[3, 4] = np.nan
+    h.set_field(0, bad)
+    with pytest.raises(np.linalg.LinAlgError):        # array.py:575-578
+        h.solve(1)
+    h.close()

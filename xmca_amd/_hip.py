@@ -1,0 +1,307 @@
+"""ctypes binding of libxmca_hip.so (C ABI: include/xmca_hip.h).
+
+The product path has no CPU fallback: importing this module without the built
+library, or creating a handle without a visible MI355X, raises.
+"""
+import ctypes
+import ctypes.util
+import os
+
+import numpy as np
+
+from . import build as _build
+
+XMCA_F32, XMCA_F64 = 0, 1
+HOST, DEVICE = 0, 1
+
+ERR_INVALID, ERR_HIP, ERR_NOT_CONVERGED, ERR_STATE, ERR_UNSUPPORTED, ERR_NUMERIC = -1, -2, -3, -4, -5, -6
+
+_c_i64 = ctypes.c_int64
+_c_int = ctypes.c_int
+_c_dbl = ctypes.c_double
+_vp = ctypes.c_void_p
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+
+# name -> (restype, argtypes); the ABI test checks every one of these is exported
+SIGNATURES = {
+    "xmca_version": (ctypes.c_char_p, []),
+    "xmca_device_count": (_c_int, []),
+    "xmca_create": (_c_int, [_c_int, ctypes.POINTER(_vp)]),
+    "xmca_destroy": (None, [_vp]),
+    "xmca_last_error": (ctypes.c_char_p, [_vp]),
+    "xmca_set_field": (_c_int, [_vp, _c_int, _vp, _vp, _c_i64, _c_i64, _c_int, _c_int]),
+    "xmca_complexify": (_c_int, [_vp, _vp]),
+    "xmca_solve": (_c_int, [_vp, _c_int, _c_i64, ctypes.POINTER(_c_i64)]),
+    "xmca_get_singular_values": (_c_int, [_vp, _vp, _c_i64]),
+    "xmca_get_vectors": (_c_int, [_vp, _c_int, _vp, _c_i64, _c_int]),
+    "xmca_is_complex": (_c_int, [_vp]),
+    "xmca_rotate_loadings": (_c_int, [_vp, _vp, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_dbl, _c_int, _c_int,
+                                      _vp, _vp, _vp, _vp, _vp, _ip]),
+    "xmca_rule_n": (_c_int, [_vp, _c_i64, _c_i64, _c_i64, _c_int, _vp, _c_int, _c_int, _c_int, _c_dbl, _c_i64, _c_i64,
+                             ctypes.c_uint64, _c_int, _vp, _vp, _c_i64]),
+    "xmca_surrogate": (_c_int, [_vp, _c_i64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _vp]),
+    "xmca_get_timings": (_c_int, [_vp, ctypes.c_char_p, _c_int, _vp, _c_int]),
+    "xmca_reset_timings": (_c_int, [_vp]),
+    "xmca_gemm": (_c_int, [_vp, _vp, _c_i64, _c_int, _vp, _c_i64, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_dbl,
+                           _c_int, _c_int, _c_int]),
+    "xmca_eigh": (_c_int, [_vp, _vp, _c_int, _c_int, _vp, _vp, _vp]),
+    "xmca_bench_gram": (_c_int, [_vp, _c_int, _c_int, _dp, _dp, _dp]),
+}
+
+_lib = None
+
+
+def library_path():
+    return _build.LIB
+
+
+def load_library():
+    """Loads (building first if the sources are newer and hipcc is present)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            "xmca_amd: %s is missing. Build it with `python -m xmca_amd.build` (needs hipcc, "
+            "--offload-arch=gfx950). There is no CPU fallback." % path)
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class HipError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(message)
+        self.code = code
+
+
+def _raise(code, message):
+    if code == ERR_INVALID:
+        raise ValueError(message)
+    if code == ERR_NOT_CONVERGED:
+        raise RuntimeError(message)
+    if code == ERR_UNSUPPORTED:
+        raise NotImplementedError(message)
+    if code == ERR_NUMERIC:
+        raise np.linalg.LinAlgError(message)
+    raise HipError(code, message)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+def _np_dtype_code(dt):
+    dt = np.dtype(dt)
+    if dt in (np.float32, np.complex64):
+        return XMCA_F32
+    if dt in (np.float64, np.complex128):
+        return XMCA_F64
+    raise TypeError("unsupported dtype %s (float32 / float64 / complex64 / complex128 only)" % dt)
+
+
+def hilbert_imag_column(T):
+    """First column of the imaginary part of the analytic-signal operator of scipy.signal.hilbert (axis 0).
+
+    hilbert(x) = ifft(fft(x) * h) with h = [1, 2, ..., 2, (1), 0, ...]; its imaginary part acts on a real x as the
+    real circulant matrix Ht[t, s] = col[(t - s) mod T] with col = imag(ifft(h)).
+    """
+    h = np.zeros(T)
+    if T % 2 == 0:
+        h[0] = h[T // 2] = 1.0
+        h[1:T // 2] = 2.0
+    else:
+        h[0] = 1.0
+        h[1:(T + 1) // 2] = 2.0
+    return np.ascontiguousarray(np.fft.ifft(h).imag)
+
+
+def hilbert_imag_operator(T):
+    """The full T x T operator (tests / documentation)."""
+    col = hilbert_imag_column(T)
+    idx = (np.arange(T)[:, None] - np.arange(T)[None, :]) % T
+    return np.ascontiguousarray(col[idx])
+
+
+class Handle:
+    """One device + stream + workspace.  Not thread-safe."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        self._h = _vp()
+        n = self._lib.xmca_device_count()
+        if n <= 0:
+            raise HipError(ERR_HIP, "xmca_amd: no HIP device visible (MI355X / gfx950 required; there is no CPU fallback)")
+        rc = self._lib.xmca_create(int(device), ctypes.byref(self._h))
+        if rc != 0:
+            raise HipError(rc, "xmca_create(device=%d) failed" % device)
+        self.device = device
+        self._keep = []      # host / device buffers that must outlive the handle's use of them
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.xmca_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self._lib.xmca_last_error(self._h)
+            _raise(rc, msg.decode("utf-8", "replace") if msg else "xmca error %d" % rc)
+
+    # ---- fields -------------------------------------------------------------------------------
+    def set_field(self, side, field):
+        """field: T x N numpy array (real or complex, float32/float64 based)."""
+        field = np.asarray(field)
+        if field.ndim != 2:
+            raise ValueError("field must be 2-D (time x space)")
+        code = _np_dtype_code(field.dtype)
+        T, N = field.shape
+        if np.iscomplexobj(field):
+            re = np.ascontiguousarray(field.real)
+            im = np.ascontiguousarray(field.imag)
+        else:
+            re = np.ascontiguousarray(field)
+            im = None
+        self._check(self._lib.xmca_set_field(self._h, side, _ptr(re), _ptr(im), T, N, code, HOST))
+
+    def set_field_device(self, side, re_ptr, im_ptr, T, N, dtype):
+        """Adopt device pointers (e.g. torch tensors' data_ptr()); the caller keeps them alive."""
+        self._check(self._lib.xmca_set_field(self._h, side, _vp(re_ptr), _vp(im_ptr) if im_ptr else None, T, N,
+                                             _np_dtype_code(dtype), DEVICE))
+
+    def complexify(self, T):
+        ht = hilbert_imag_column(T)
+        self._check(self._lib.xmca_complexify(self._h, _ptr(ht)))
+
+    # ---- solve --------------------------------------------------------------------------------
+    def solve(self, n_fields, n_vec=-1):
+        rank = _c_i64(0)
+        self._check(self._lib.xmca_solve(self._h, n_fields, n_vec, ctypes.byref(rank)))
+        return int(rank.value)
+
+    def singular_values(self, n):
+        out = np.empty(n, dtype=np.float64)
+        self._check(self._lib.xmca_get_singular_values(self._h, _ptr(out), n))
+        return out
+
+    def vectors(self, side, n_modes, N, dtype):
+        """Returns Vt (n_modes x N); V = Vt.T."""
+        cplx = bool(self._lib.xmca_is_complex(self._h))
+        code = _np_dtype_code(dtype)
+        base = np.float32 if code == XMCA_F32 else np.float64
+        if cplx:
+            out = np.empty((n_modes, N), dtype=np.complex64 if code == XMCA_F32 else np.complex128)
+        else:
+            out = np.empty((n_modes, N), dtype=base)
+        self._check(self._lib.xmca_get_vectors(self._h, side, _ptr(out), n_modes, code))
+        return out
+
+    # ---- rotation -----------------------------------------------------------------------------
+    def rotate_loadings(self, L, n_left, power=1, tol=1e-8, max_iter=1000, varimax_only=False, want_B=False):
+        L = np.asarray(L)
+        cplx = np.iscomplexobj(L)
+        Ld = np.ascontiguousarray(L, dtype=np.complex128 if cplx else np.float64)
+        N, p = Ld.shape
+        cdt = np.complex128 if cplx else np.float64
+        R = np.empty((p, p), dtype=cdt)
+        Phi = np.empty((p, p), dtype=cdt)
+        nl = np.zeros(p)
+        nr = np.zeros(p)
+        B = np.empty((N, p), dtype=cdt) if want_B else None
+        iters = _c_int(0)
+        rc = self._lib.xmca_rotate_loadings(self._h, _ptr(Ld), N, int(n_left), p, int(cplx), int(power), float(tol),
+                                            int(max_iter), int(varimax_only), _ptr(B), _ptr(R), _ptr(Phi), _ptr(nl),
+                                            _ptr(nr), ctypes.byref(iters))
+        self.last_iters = int(iters.value)
+        self._check(rc)
+        return {"B": B, "R": R, "Phi": Phi, "norm_left": nl, "norm_right": nr, "n_iter": int(iters.value)}
+
+    # ---- rule N -------------------------------------------------------------------------------
+    def rule_n(self, T, Nx, Ny, n_fields, complexify, rotated, p, power, tol, run_begin, run_end, seed, dtype, n_out):
+        n = run_end - run_begin
+        spectra = np.zeros((max(n, 0), n_out), dtype=np.float64)
+        kept = np.zeros(max(n, 0), dtype=np.int32)
+        ht = hilbert_imag_column(T) if complexify else None
+        if n > 0:
+            self._check(self._lib.xmca_rule_n(self._h, T, Nx, Ny if n_fields == 2 else 0, n_fields, _ptr(ht), int(rotated),
+                                              int(p), int(power), float(tol), run_begin, run_end, int(seed),
+                                              _np_dtype_code(dtype), _ptr(spectra), _ptr(kept), n_out))
+        return spectra, kept
+
+    def surrogate(self, n, seed, run, side):
+        out = np.empty(n, dtype=np.float64)
+        self._check(self._lib.xmca_surrogate(self._h, n, int(seed), int(run), int(side), _ptr(out)))
+        return out
+
+    # ---- instrumentation ----------------------------------------------------------------------
+    def timings(self):
+        names = ctypes.create_string_buffer(4096)
+        ms = np.zeros(64)
+        n = self._lib.xmca_get_timings(self._h, names, 4096, _ptr(ms), 64)
+        if n < 0:
+            self._check(n)
+        keys = names.value.decode().split(";") if n > 0 else []
+        return {k: float(ms[i]) for i, k in enumerate(keys[:n])}
+
+    def reset_timings(self):
+        self._check(self._lib.xmca_reset_timings(self._h))
+
+    # ---- kernel-level entry points --------------------------------------------------------------
+    def gemm(self, A, B, a_kfast=True, b_nfast=True, alpha=1.0, upper_only=False, mirror=0, splits=0):
+        """C = alpha * op(A) op(B); A: (M,K) if a_kfast else (K,M); B: (K,N) if b_nfast else (N,K)."""
+        A = np.ascontiguousarray(A)
+        B = np.ascontiguousarray(B, dtype=A.dtype)
+        code = _np_dtype_code(A.dtype)
+        M, K = A.shape if a_kfast else A.shape[::-1]
+        Kb, N = B.shape if b_nfast else B.shape[::-1]
+        if K != Kb:
+            raise ValueError("gemm: inner dimensions differ")
+        C = np.zeros((M, N), dtype=np.float64)
+        self._check(self._lib.xmca_gemm(self._h, _ptr(A), A.shape[1], int(a_kfast), _ptr(B), B.shape[1], int(b_nfast),
+                                        _ptr(C), M, N, K, code, float(alpha), int(upper_only), int(mirror), int(splits)))
+        return C
+
+    def eigh(self, A):
+        """Returns (lam descending, U) with A = U diag(lam) U^H."""
+        A = np.asarray(A)
+        cplx = np.iscomplexobj(A)
+        Ad = np.ascontiguousarray(A, dtype=np.complex128 if cplx else np.float64)
+        n = Ad.shape[0]
+        lam = np.empty(n)
+        Zh = np.empty((n, n), dtype=Ad.dtype)
+        info = np.zeros(3, dtype=np.int32)
+        self._check(self._lib.xmca_eigh(self._h, _ptr(Ad), n, int(cplx), _ptr(lam), _ptr(Zh), _ptr(info)))
+        self.last_eigh_info = {"sweeps": int(info[0]), "tile": int(info[1]), "slots": int(info[2])}
+        return lam, Zh.conj().T
+
+    def bench_gram(self, side, reps):
+        a, k, f = _c_dbl(0), _c_dbl(0), _c_dbl(0)
+        self._check(self._lib.xmca_bench_gram(self._h, side, reps, ctypes.byref(a), ctypes.byref(k), ctypes.byref(f)))
+        return {"avg_ms": a.value, "kernel_ms": k.value, "flops": f.value}
+
+
+_default = {}
+
+
+def default_handle(device=None):
+    """Process-wide handle per device (LOCAL_RANK selects the device when not given)."""
+    if device is None:
+        device = int(os.environ.get("XMCA_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        n = load_library().xmca_device_count()
+        if n > 0:
+            device %= n
+    if device not in _default:
+        _default[device] = Handle(device)
+    return _default[device]

@@ -1,0 +1,159 @@
+// Streaming (HBM-bound) helper kernels: conversions, plane packing, row/column scaling, row
+// normalisation, column centering and the Philox surrogate generator.
+#pragma once
+#include "common.h"
+
+namespace xmca {
+
+constexpr int EW_BLOCK = 256;
+static inline dim3 ew_grid(int64_t n, int per_thread = 1) {
+  int64_t b = (n + (int64_t)EW_BLOCK * per_thread - 1) / ((int64_t)EW_BLOCK * per_thread);
+  if (b > 8192) b = 8192;   // grid-stride beyond that
+  if (b < 1) b = 1;
+  return dim3((unsigned)b);
+}
+
+template <typename TI, typename TO>
+__global__ void convert_kernel(const TI* __restrict__ in, TO* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = (TO)in[i];
+}
+
+// interleaved complex (re,im,re,im,...) -> two planes
+template <typename TI, typename TO>
+__global__ void split_complex_kernel(const TI* __restrict__ in, TO* __restrict__ re, TO* __restrict__ im, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    re[i] = (TO)in[2 * i];
+    im[i] = (TO)in[2 * i + 1];
+  }
+}
+
+// rows x cols block of planes (ld) -> dense output: real (im == nullptr) or interleaved complex; optional conj
+template <typename TO>
+__global__ void pack_rows_kernel(const double* __restrict__ re, const double* __restrict__ im, int64_t ld, int rows, int cols,
+                                 TO* __restrict__ out, int conj) {
+  const int64_t n = (int64_t)rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols, c = i % cols;
+    const double vr = re[r * ld + c];
+    if (im) {
+      const double vi = im[r * ld + c];
+      out[2 * i] = (TO)vr;
+      out[2 * i + 1] = (TO)(conj ? -vi : vi);
+    } else {
+      out[i] = (TO)vr;
+    }
+  }
+}
+
+// X[r][c] *= s[r] (by_row) or s[c]; both planes
+__global__ void scale_kernel(double* __restrict__ re, double* __restrict__ im, int64_t ld, int rows, int cols,
+                             const double* __restrict__ s, int by_row, int invert) {
+  const int64_t n = (int64_t)rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols, c = i % cols;
+    double f = s[by_row ? r : c];
+    if (invert) f = 1.0 / f;
+    re[r * ld + c] *= f;
+    if (im) im[r * ld + c] *= f;
+  }
+}
+
+// Ht[t][s] = col[(t - s) mod T]  (circulant operator from its first column)
+template <typename TO>
+__global__ void circulant_kernel(const double* __restrict__ col, int T, TO* __restrict__ out) {
+  const int64_t n = (int64_t)T * T;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int t = (int)(i / T), s = (int)(i % T);
+    int d = t - s;
+    if (d < 0) d += T;
+    out[i] = (TO)col[d];
+  }
+}
+
+__global__ void sqrt_clamp_kernel(const double* __restrict__ lam, double* __restrict__ s, int n, double scale) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) s[i] = sqrt(fmax(lam[i] * scale, 0.0));
+}
+
+__device__ __forceinline__ double block_sum_256(double v, double* red) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  const int tid = threadIdx.x;
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// one workgroup per row: row <- conj?(row) / ||row||   (planes, f64).  norms_out (nullable) gets ||row||.
+template <typename T>
+__global__ __launch_bounds__(256) void normalize_rows_kernel(T* __restrict__ re, T* __restrict__ im, int64_t ld, int cols,
+                                                             int conj, double* __restrict__ norms_out) {
+  __shared__ double red[4];
+  const int64_t r = blockIdx.x;
+  double acc = 0.0;
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    const double a = (double)re[r * ld + c];
+    acc += a * a;
+    if (im) {
+      const double b = (double)im[r * ld + c];
+      acc += b * b;
+    }
+  }
+  const double nrm = sqrt(block_sum_256(acc, red));
+  const double inv = nrm > 0.0 ? 1.0 / nrm : 0.0;
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    re[r * ld + c] = (T)((double)re[r * ld + c] * inv);
+    if (im) im[r * ld + c] = (T)((double)im[r * ld + c] * (conj ? -inv : inv));
+  }
+  if (norms_out && threadIdx.x == 0) norms_out[r] = nrm;
+}
+
+// column means of a T x N row-major matrix, then subtraction.  One thread per column (coalesced across threads).
+template <typename T>
+__global__ void center_columns_kernel(T* __restrict__ x, int rows, int64_t cols) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  double s = 0.0;
+  for (int r = 0; r < rows; ++r) s += (double)x[(int64_t)r * cols + c];
+  const double m = s / rows;
+  for (int r = 0; r < rows; ++r) x[(int64_t)r * cols + c] = (T)((double)x[(int64_t)r * cols + c] - m);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Philox4x32-10 counter-based generator (Salmon et al. 2011) -> standard normals (Box-Muller).
+// counter = (element pair index lo, hi, run, side), key = seed: the stream of a surrogate depends only on
+// (seed, run, side), never on which GPU generates it.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t out[4]) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+    const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += W0; k1 += W1;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+template <typename T>
+__global__ void philox_normal_kernel(T* __restrict__ out, int64_t n, uint64_t seed, uint32_t run, uint32_t side) {
+  const int64_t pairs = (n + 1) / 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)i, (uint32_t)((uint64_t)i >> 32), run, side, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    const uint64_t a = ((uint64_t)r[0] << 32) | r[1], b = ((uint64_t)r[2] << 32) | r[3];
+    const double u1 = ((double)(a >> 11) + 0.5) * (1.0 / 9007199254740992.0);   // (0,1)
+    const double u2 = ((double)(b >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+    const double rad = sqrt(-2.0 * log(u1));
+    double sn, cs;
+    sincospi(2.0 * u2, &sn, &cs);
+    out[2 * i] = (T)(rad * cs);
+    if (2 * i + 1 < n) out[2 * i + 1] = (T)(rad * sn);
+  }
+}
+
+}  // namespace xmca

@@ -1,0 +1,511 @@
+// C ABI of libxmca_hip.so (see include/xmca_hip.h).  Compiled for gfx950 only.
+#include "../../include/xmca_hip.h"
+
+#include <cstring>
+#include <string>
+#include <type_traits>
+
+#include "solver.h"
+
+using namespace xmca;
+
+struct xmca_handle {
+  int device = 0;
+  hipStream_t st = nullptr;
+  std::string err;
+  GemmWorkspace gws;
+  EvdWorkspace ews;
+  StageTimer tm;
+  int dtype = -1;
+  FieldData<float> f32[2];
+  FieldData<double> f64[2];
+  bool field_set[2] = {false, false};
+  SolveResult res;
+  bool solved = false;
+  RotationDevice rot;
+};
+
+#define API_BEGIN(h)                                                   \
+  if (!(h)) return XMCA_ERR_INVALID;                                   \
+  try {                                                                \
+    XMCA_HIP(hipSetDevice((h)->device));
+#define API_END(h)                                                     \
+  }                                                                    \
+  catch (const ::xmca::Error& e) {                                     \
+    (h)->err = e.what();                                               \
+    (void)hipGetLastError();                                           \
+    return e.code;                                                     \
+  }                                                                    \
+  catch (const std::exception& e) {                                    \
+    (h)->err = std::string("unexpected: ") + e.what();                 \
+    return XMCA_ERR_HIP;                                               \
+  }                                                                    \
+  return XMCA_OK;
+
+extern "C" {
+
+const char* xmca_version(void) { return "xmca_amd 0.1.0 (gfx950)"; }
+
+int xmca_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+
+int xmca_create(int device, xmca_handle** out) {
+  if (!out) return XMCA_ERR_INVALID;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) { (void)hipGetLastError(); return XMCA_ERR_HIP; }
+  if (hipSetDevice(device) != hipSuccess) return XMCA_ERR_HIP;
+  xmca_handle* h = new xmca_handle();
+  h->device = device;
+  if (hipStreamCreate(&h->st) != hipSuccess) { delete h; return XMCA_ERR_HIP; }
+  h->tm.st = h->st;
+  *out = h;
+  return XMCA_OK;
+}
+
+void xmca_destroy(xmca_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->st);
+  try { h->tm.reset(); } catch (...) {}
+  (void)hipStreamDestroy(h->st);
+  delete h;
+}
+
+const char* xmca_last_error(xmca_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+}  // extern "C"
+
+namespace {
+
+template <typename TI>
+FieldData<TI>* fields_of(xmca_handle* h);
+template <>
+FieldData<float>* fields_of<float>(xmca_handle* h) { return h->f32; }
+template <>
+FieldData<double>* fields_of<double>(xmca_handle* h) { return h->f64; }
+
+template <typename TI>
+void set_field_impl(xmca_handle* h, int side, const void* re, const void* im, int64_t T, int64_t N, int location) {
+  FieldData<TI>& f = fields_of<TI>(h)[side];
+  const size_t n = (size_t)T * N;
+  f.T = T; f.N = N;
+  f.has_im = im != nullptr;
+  f.ext_re = nullptr; f.ext_im = nullptr;
+  if (location == XMCA_DEVICE) {
+    f.ext_re = static_cast<const TI*>(re);
+    f.ext_im = static_cast<const TI*>(im);
+  } else {
+    XMCA_HIP(hipMemcpyAsync(f.re.ensure(n), re, n * sizeof(TI), hipMemcpyHostToDevice, h->st));
+    if (im) XMCA_HIP(hipMemcpyAsync(f.im.ensure(n), im, n * sizeof(TI), hipMemcpyHostToDevice, h->st));
+    XMCA_HIP(hipStreamSynchronize(h->st));
+  }
+}
+
+// T x T circulant Hilbert operator in the field's element type, from its first column (host)
+template <typename TI>
+void build_hilbert(xmca_handle* h, const double* col_host, int64_t T, DevBuf<TI>& ht) {
+  DevBuf<double> col;
+  XMCA_HIP(hipMemcpyAsync(col.ensure((size_t)T), col_host, sizeof(double) * T, hipMemcpyHostToDevice, h->st));
+  hipLaunchKernelGGL((circulant_kernel<TI>), ew_grid(T * T), dim3(EW_BLOCK), 0, h->st, col.get(), (int)T, ht.ensure((size_t)T * T));
+  XMCA_HIP(hipGetLastError());
+  XMCA_HIP(hipStreamSynchronize(h->st));
+}
+
+template <typename TI>
+void complexify_impl(xmca_handle* h, const double* col_host) {
+  FieldData<TI>* f = fields_of<TI>(h);
+  const int64_t T = f[0].T;
+  DevBuf<TI> htb;
+  build_hilbert<TI>(h, col_host, T, htb);
+  struct { const TI* r; } ht{htb.get()};
+  h->tm.begin("hilbert");
+  for (int s = 0; s < 2; ++s) {
+    if (!h->field_set[s]) continue;
+    GemmOpts o;   // X_im = Ht X   (T x T) (T x N)
+    TI* dst = f[s].im.ensure((size_t)T * f[s].N);
+    gemm<TI, TI>(h->st, h->gws, ht.r, T, f[s].r(), f[s].N, dst, f[s].N, (int)T, (int)f[s].N, (int)T, o);
+    f[s].has_im = true;
+    f[s].ext_im = nullptr;
+  }
+  h->tm.end();
+  XMCA_HIP(hipStreamSynchronize(h->st));
+}
+
+template <typename TI>
+void solve_impl(xmca_handle* h, int n_fields, int64_t n_vec) {
+  FieldData<TI>* f = fields_of<TI>(h);
+  const bool cplx = f[0].has_im;
+  if (n_fields == 2) XMCA_CHECK(f[1].has_im == cplx, XMCA_ERR_INVALID, "solve: both fields must be real or both complex");
+  Solver<TI> s(h->st, h->gws, h->ews, h->tm);
+  s.solve(f, n_fields, cplx, (int)n_vec, h->res);
+}
+
+template <typename TO>
+void get_vectors_impl(xmca_handle* h, int side, void* out, int64_t m) {
+  const SolveResult& r = h->res;
+  const int64_t N = r.ldv[side];
+  const bool cplx = r.cplx;
+  const size_t n_out = (size_t)m * N * (cplx ? 2 : 1);
+  DevBuf<TO> tmp;
+  tmp.ensure(n_out);
+  hipLaunchKernelGGL((pack_rows_kernel<TO>), ew_grid((int64_t)m * N), dim3(EW_BLOCK), 0, h->st, r.Vt[side].r(), r.Vt[side].i(cplx), N,
+                     (int)m, (int)N, tmp.get(), 0);
+  XMCA_HIP(hipGetLastError());
+  XMCA_HIP(hipMemcpyAsync(out, tmp.get(), n_out * sizeof(TO), hipMemcpyDeviceToHost, h->st));
+  XMCA_HIP(hipStreamSynchronize(h->st));
+}
+
+void fill_rot_outputs(const RotateResult& rr, bool cplx, double* R_out, double* Phi_out, double* nl, double* nr, int* iters) {
+  const int p = rr.p;
+  if (iters) *iters = rr.iters;
+  for (int e = 0; e < p * p; ++e) {
+    if (cplx) {
+      if (R_out) { R_out[2 * e] = rr.R[e].real(); R_out[2 * e + 1] = rr.R[e].imag(); }
+      if (Phi_out) { Phi_out[2 * e] = rr.Phi[e].real(); Phi_out[2 * e + 1] = rr.Phi[e].imag(); }
+    } else {
+      if (R_out) R_out[e] = rr.R[e].real();
+      if (Phi_out) Phi_out[e] = rr.Phi[e].real();
+    }
+  }
+  for (int k = 0; k < p; ++k) {
+    if (nl && !rr.norm_left.empty()) nl[k] = rr.norm_left[k];
+    if (nr && !rr.norm_right.empty()) nr[k] = rr.norm_right[k];
+  }
+}
+
+void check_rot(const RotateResult& rr) {
+  XMCA_CHECK(!rr.nan, XMCA_ERR_NUMERIC, "varimax: NaN encountered (zero or NaN rows in the loadings?)");
+  XMCA_CHECK(rr.converged, XMCA_ERR_NOT_CONVERGED,
+             "Rotation process did not converge. Try decreasing the tolerance. Invalid NaN entries also might be a problem.");
+}
+
+template <typename TI>
+void rule_n_impl(xmca_handle* h, int64_t T, int64_t Nx, int64_t Ny, int n_fields, const double* ht_host, int rotated, int p,
+                 int power, double tol, int64_t run_begin, int64_t run_end, uint64_t seed, double* spectra, int* kept,
+                 int64_t n_out) {
+  FieldData<TI> f[2];
+  const int64_t Ns[2] = {Nx, Ny};
+  DevBuf<TI> htb;
+  const bool cplx = ht_host != nullptr;
+  if (cplx) build_hilbert<TI>(h, ht_host, T, htb);
+  struct { const TI* r; } ht{htb.get()};
+  Solver<TI> solver(h->st, h->gws, h->ews, h->tm);
+  Rotator rot(h->st, h->tm);
+  SolveResult res;
+  RotationDevice rd;
+  DevBuf<double> sigma_dev;
+  const int64_t rank = std::min(T, n_fields == 2 ? std::min(Nx, Ny) : Nx);
+  XMCA_CHECK(n_out == (rotated ? (int64_t)p : rank), XMCA_ERR_INVALID, "rule_n: n_out must be rank (unrotated) or p (rotated)");
+  for (int64_t run = run_begin; run < run_end; ++run) {
+    h->tm.begin("surrogate");
+    for (int s = 0; s < n_fields; ++s) {
+      f[s].T = T; f[s].N = Ns[s]; f[s].has_im = false;
+      const int64_t n = T * Ns[s];
+      TI* x = f[s].re.ensure((size_t)n);
+      hipLaunchKernelGGL((philox_normal_kernel<TI>), ew_grid((n + 1) / 2), dim3(EW_BLOCK), 0, h->st, x, n, seed, (uint32_t)run,
+                         (uint32_t)s);
+      hipLaunchKernelGGL((center_columns_kernel<TI>), dim3(ceil_div(Ns[s], 256)), dim3(256), 0, h->st, x, (int)T, Ns[s]);
+      XMCA_HIP(hipGetLastError());
+      if (cplx) {
+        GemmOpts o;
+        gemm<TI, TI>(h->st, h->gws, ht.r, T, x, Ns[s], f[s].im.ensure((size_t)n), Ns[s], (int)T, (int)Ns[s], (int)T, o);
+        f[s].has_im = true;
+      }
+    }
+    h->tm.end();
+    solver.solve(f, n_fields, cplx, rotated ? p : 0, res);
+    double* out = spectra + (run - run_begin) * n_out;
+    kept[run - run_begin] = 1;
+    if (!rotated) {
+      for (int64_t i = 0; i < n_out; ++i) out[i] = res.sigma[i];
+      continue;
+    }
+    // rotate the first p modes (array.py:815-833)
+    const int64_t Nl = Ns[0], Nr = n_fields == 2 ? Ns[1] : 0;
+    rot.alloc(rd, Nl + Nr, Nl, p, cplx);
+    XMCA_HIP(hipMemcpyAsync(sigma_dev.ensure((size_t)p), res.sigma.data(), sizeof(double) * p, hipMemcpyHostToDevice, h->st));
+    const CPlanes& Vl = res.Vt[0];
+    const CPlanes& Vr = res.Vt[n_fields == 2 ? 1 : 0];
+    RotateResult rr;
+    if (cplx) {
+      hipLaunchKernelGGL((rot_build_loadings_kernel<true>), ew_grid(Nl + Nr), dim3(EW_BLOCK), 0, h->st, Vl.r(), Vl.i(true), Nl, Nl,
+                         Vr.r(), Vr.i(true), Nr > 0 ? Nr : Nl, Nr, sigma_dev.get(), p, rd.A.r(), rd.A.i(true), rd.h.get());
+      rot.run<true>(rd, power, tol, 1000, rr, nullptr, false);
+    } else {
+      hipLaunchKernelGGL((rot_build_loadings_kernel<false>), ew_grid(Nl + Nr), dim3(EW_BLOCK), 0, h->st, Vl.r(), (const double*)nullptr,
+                         Nl, Nl, Vr.r(), (const double*)nullptr, Nr > 0 ? Nr : Nl, Nr, sigma_dev.get(), p, rd.A.r(), (double*)nullptr,
+                         rd.h.get());
+      rot.run<false>(rd, power, tol, 1000, rr, nullptr, false);
+    }
+    if (rr.nan || !rr.converged) {       // array.py:1762-1763: the run is silently dropped
+      kept[run - run_begin] = 0;
+      for (int64_t i = 0; i < n_out; ++i) out[i] = 0.0;
+      continue;
+    }
+    std::vector<double> var(p);
+    for (int k = 0; k < p; ++k) var[k] = n_fields == 2 ? rr.norm_left[k] * rr.norm_right[k] : rr.norm_left[k] * rr.norm_left[k];
+    std::sort(var.begin(), var.end(), [](double a, double b) { return a > b; });
+    for (int k = 0; k < p; ++k) out[k] = var[k];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int xmca_set_field(xmca_handle* h, int side, const void* re, const void* im, int64_t T, int64_t N, int dtype, int location) {
+  API_BEGIN(h)
+  XMCA_CHECK(side == 0 || side == 1, XMCA_ERR_INVALID, "set_field: side must be 0 or 1");
+  XMCA_CHECK(re && T >= 2 && N >= 1, XMCA_ERR_INVALID, "set_field: need a T x N field with T >= 2, N >= 1");
+  XMCA_CHECK(dtype == XMCA_F32 || dtype == XMCA_F64, XMCA_ERR_INVALID, "set_field: dtype must be float32 or float64");
+  XMCA_CHECK(T < (1 << 30) && N < (1ll << 31), XMCA_ERR_UNSUPPORTED, "set_field: dimension too large");
+  if (side == 0) { h->field_set[1] = false; h->dtype = dtype; }
+  else {
+    XMCA_CHECK(h->field_set[0], XMCA_ERR_STATE, "set_field: set the left field first");
+    XMCA_CHECK(dtype == h->dtype, XMCA_ERR_INVALID, "set_field: both fields must have the same dtype");
+    const int64_t T0 = dtype == XMCA_F32 ? h->f32[0].T : h->f64[0].T;
+    XMCA_CHECK(T == T0, XMCA_ERR_INVALID, "set_field: time dimensions of the fields differ");
+  }
+  if (dtype == XMCA_F32) set_field_impl<float>(h, side, re, im, T, N, location);
+  else set_field_impl<double>(h, side, re, im, T, N, location);
+  h->field_set[side] = true;
+  h->solved = false;
+  API_END(h)
+}
+
+int xmca_complexify(xmca_handle* h, const double* hilbert_col) {
+  API_BEGIN(h)
+  XMCA_CHECK(h->field_set[0] && hilbert_col, XMCA_ERR_STATE, "complexify: set a field first");
+  if (h->dtype == XMCA_F32) complexify_impl<float>(h, hilbert_col);
+  else complexify_impl<double>(h, hilbert_col);
+  h->solved = false;
+  API_END(h)
+}
+
+int xmca_solve(xmca_handle* h, int n_fields, int64_t n_vec, int64_t* rank_out) {
+  API_BEGIN(h)
+  XMCA_CHECK(n_fields == 1 || n_fields == 2, XMCA_ERR_INVALID, "solve: n_fields must be 1 or 2");
+  XMCA_CHECK(h->field_set[0] && (n_fields == 1 || h->field_set[1]), XMCA_ERR_STATE, "solve: fields not set");
+  h->solved = false;
+  if (h->dtype == XMCA_F32) solve_impl<float>(h, n_fields, n_vec);
+  else solve_impl<double>(h, n_fields, n_vec);
+  h->solved = true;
+  if (rank_out) *rank_out = h->res.rank;
+  h->tm.collect();
+  API_END(h)
+}
+
+int xmca_get_singular_values(xmca_handle* h, double* out, int64_t n) {
+  API_BEGIN(h)
+  XMCA_CHECK(h->solved, XMCA_ERR_STATE, "singular values requested before solve");
+  XMCA_CHECK(out && n >= 0 && n <= h->res.rank, XMCA_ERR_INVALID, "get_singular_values: bad size");
+  std::memcpy(out, h->res.sigma.data(), sizeof(double) * (size_t)n);
+  API_END(h)
+}
+
+int xmca_is_complex(xmca_handle* h) { return (h && h->solved && h->res.cplx) ? 1 : 0; }
+
+int xmca_get_vectors(xmca_handle* h, int side, void* out, int64_t n_modes, int dtype) {
+  API_BEGIN(h)
+  XMCA_CHECK(h->solved, XMCA_ERR_STATE, "vectors requested before solve");
+  XMCA_CHECK(side == 0 || side == 1, XMCA_ERR_INVALID, "get_vectors: side must be 0 or 1");
+  XMCA_CHECK(out && n_modes >= 0 && n_modes <= h->res.n_vec && h->res.ldv[side] > 0, XMCA_ERR_INVALID,
+             "get_vectors: more modes requested than were back-projected");
+  if (n_modes > 0) {
+    if (dtype == XMCA_F32) get_vectors_impl<float>(h, side, out, n_modes);
+    else get_vectors_impl<double>(h, side, out, n_modes);
+  }
+  API_END(h)
+}
+
+int xmca_rotate_loadings(xmca_handle* h, const double* L, int64_t N, int64_t n_left, int p, int is_complex, int power,
+                         double tol, int max_iter, int varimax_only, double* B_out, double* R_out, double* Phi_out,
+                         double* norm_left, double* norm_right, int* iters_out) {
+  API_BEGIN(h)
+  XMCA_CHECK(L && N >= 1 && p >= 2, XMCA_ERR_INVALID, "rotate: need N x p loadings with p >= 2");
+  XMCA_CHECK(power >= 1, XMCA_ERR_INVALID, "rotate: `power` must be >= 1");
+  XMCA_CHECK(n_left >= 0 && n_left <= N && max_iter >= 1, XMCA_ERR_INVALID, "rotate: bad n_left / max_iter");
+  const bool cplx = is_complex != 0;
+  Rotator rot(h->st, h->tm);
+  RotationDevice& d = h->rot;
+  rot.alloc(d, N, n_left, p, cplx);
+  const size_t nl = (size_t)N * p * (cplx ? 2 : 1);
+  DevBuf<double> Ld, Bd;
+  XMCA_HIP(hipMemcpyAsync(Ld.ensure(nl), L, sizeof(double) * nl, hipMemcpyHostToDevice, h->st));
+  if (B_out) Bd.ensure(nl);
+  RotateResult rr;
+  if (cplx) {
+    hipLaunchKernelGGL((rot_import_loadings_kernel<true>), ew_grid(N), dim3(EW_BLOCK), 0, h->st, Ld.get(), N, p, d.A.r(), d.A.i(true),
+                       d.h.get());
+    rot.run<true>(d, power, tol, max_iter, rr, B_out ? Bd.get() : nullptr, varimax_only != 0);
+  } else {
+    hipLaunchKernelGGL((rot_import_loadings_kernel<false>), ew_grid(N), dim3(EW_BLOCK), 0, h->st, Ld.get(), N, p, d.A.r(),
+                       (double*)nullptr, d.h.get());
+    rot.run<false>(d, power, tol, max_iter, rr, B_out ? Bd.get() : nullptr, varimax_only != 0);
+  }
+  h->tm.collect();
+  if (iters_out) *iters_out = rr.iters;
+  check_rot(rr);
+  fill_rot_outputs(rr, cplx, R_out, Phi_out, norm_left, norm_right, iters_out);
+  if (B_out) {
+    XMCA_HIP(hipMemcpyAsync(B_out, Bd.get(), sizeof(double) * nl, hipMemcpyDeviceToHost, h->st));
+    XMCA_HIP(hipStreamSynchronize(h->st));
+  }
+  API_END(h)
+}
+
+int xmca_rule_n(xmca_handle* h, int64_t T, int64_t Nx, int64_t Ny, int n_fields, const double* hilbert_col, int rotated,
+                int p, int power, double tol, int64_t run_begin, int64_t run_end, uint64_t seed, int dtype,
+                double* spectra_out, int* kept_out, int64_t n_out) {
+  API_BEGIN(h)
+  XMCA_CHECK(n_fields == 1 || n_fields == 2, XMCA_ERR_INVALID, "rule_n: n_fields must be 1 or 2");
+  XMCA_CHECK(T >= 2 && Nx >= 1 && (n_fields == 1 || Ny >= 1), XMCA_ERR_INVALID, "rule_n: bad field shape");
+  XMCA_CHECK(run_end >= run_begin && spectra_out && kept_out, XMCA_ERR_INVALID, "rule_n: bad run range / outputs");
+  XMCA_CHECK(!rotated || (p >= 2 && power >= 1), XMCA_ERR_INVALID, "rule_n: bad rotation parameters");
+  if (dtype == XMCA_F32)
+    rule_n_impl<float>(h, T, Nx, Ny, n_fields, hilbert_col, rotated, p, power, tol, run_begin, run_end, seed, spectra_out,
+                       kept_out, n_out);
+  else
+    rule_n_impl<double>(h, T, Nx, Ny, n_fields, hilbert_col, rotated, p, power, tol, run_begin, run_end, seed, spectra_out,
+                        kept_out, n_out);
+  h->tm.collect();
+  API_END(h)
+}
+
+int xmca_surrogate(xmca_handle* h, int64_t n, uint64_t seed, uint32_t run, uint32_t side, double* out) {
+  API_BEGIN(h)
+  XMCA_CHECK(n >= 1 && out, XMCA_ERR_INVALID, "surrogate: bad arguments");
+  DevBuf<double> d;
+  hipLaunchKernelGGL((philox_normal_kernel<double>), ew_grid((n + 1) / 2), dim3(EW_BLOCK), 0, h->st, d.ensure((size_t)n), n, seed, run,
+                     side);
+  XMCA_HIP(hipGetLastError());
+  XMCA_HIP(hipMemcpyAsync(out, d.get(), sizeof(double) * n, hipMemcpyDeviceToHost, h->st));
+  XMCA_HIP(hipStreamSynchronize(h->st));
+  API_END(h)
+}
+
+int xmca_get_timings(xmca_handle* h, char* names, int names_len, double* ms, int max_n) {
+  if (!h) return XMCA_ERR_INVALID;
+  try { h->tm.collect(); } catch (...) { return XMCA_ERR_HIP; }
+  std::string joined;
+  int n = 0;
+  for (const auto& name : h->tm.order) {
+    if (n >= max_n) break;
+    if (n) joined += ";";
+    joined += name;
+    if (ms) ms[n] = h->tm.ms[name];
+    ++n;
+  }
+  if (names && names_len > 0) {
+    std::strncpy(names, joined.c_str(), (size_t)names_len - 1);
+    names[names_len - 1] = 0;
+  }
+  return n;
+}
+
+int xmca_reset_timings(xmca_handle* h) {
+  if (!h) return XMCA_ERR_INVALID;
+  try { h->tm.reset(); } catch (...) { return XMCA_ERR_HIP; }
+  return XMCA_OK;
+}
+
+int xmca_gemm(xmca_handle* h, const void* A, int64_t lda, int a_kfast, const void* B, int64_t ldb, int b_nfast, double* C, int M,
+              int N, int K, int dtype, double alpha, int upper_only, int mirror, int splits) {
+  API_BEGIN(h)
+  XMCA_CHECK(A && B && C && M > 0 && N > 0 && K >= 0, XMCA_ERR_INVALID, "gemm: bad arguments");
+  const size_t na = (size_t)(a_kfast ? M : K) * lda, nb = (size_t)(b_nfast ? K : N) * ldb;
+  const size_t es = dtype == XMCA_F32 ? 4 : 8;
+  DevBuf<char> Ad, Bd;
+  DevBuf<double> Cd;
+  XMCA_HIP(hipMemcpyAsync(Ad.ensure(na * es), A, na * es, hipMemcpyHostToDevice, h->st));
+  XMCA_HIP(hipMemcpyAsync(Bd.ensure(nb * es), B, nb * es, hipMemcpyHostToDevice, h->st));
+  Cd.ensure((size_t)M * N);
+  XMCA_HIP(hipMemsetAsync(Cd.get(), 0, sizeof(double) * (size_t)M * N, h->st));
+  GemmOpts o;
+  o.a_kfast = a_kfast != 0; o.b_nfast = b_nfast != 0; o.alpha = alpha; o.upper_only = upper_only != 0; o.mirror = mirror;
+  o.force_splits = splits;
+  if (dtype == XMCA_F32)
+    gemm<float, double>(h->st, h->gws, reinterpret_cast<const float*>(Ad.get()), lda, reinterpret_cast<const float*>(Bd.get()), ldb,
+                        Cd.get(), N, M, N, K, o);
+  else
+    gemm<double, double>(h->st, h->gws, reinterpret_cast<const double*>(Ad.get()), lda, reinterpret_cast<const double*>(Bd.get()),
+                         ldb, Cd.get(), N, M, N, K, o);
+  XMCA_HIP(hipMemcpyAsync(C, Cd.get(), sizeof(double) * (size_t)M * N, hipMemcpyDeviceToHost, h->st));
+  XMCA_HIP(hipStreamSynchronize(h->st));
+  API_END(h)
+}
+
+int xmca_eigh(xmca_handle* h, const double* A, int n, int is_complex, double* lam, double* Zh, int* info) {
+  API_BEGIN(h)
+  XMCA_CHECK(A && n >= 1 && lam, XMCA_ERR_INVALID, "eigh: bad arguments");
+  const bool cplx = is_complex != 0;
+  const size_t nn = (size_t)n * n;
+  DevBuf<double> raw, zout;
+  CPlanes Ap, Zp;
+  Ap.ensure(nn, cplx);
+  Zp.ensure(nn, cplx);
+  if (cplx) {
+    XMCA_HIP(hipMemcpyAsync(raw.ensure(2 * nn), A, sizeof(double) * 2 * nn, hipMemcpyHostToDevice, h->st));
+    hipLaunchKernelGGL((split_complex_kernel<double, double>), ew_grid((int64_t)nn), dim3(EW_BLOCK), 0, h->st, raw.get(), Ap.r(),
+                       Ap.im.get(), (int64_t)nn);
+  } else {
+    XMCA_HIP(hipMemcpyAsync(Ap.r(), A, sizeof(double) * nn, hipMemcpyHostToDevice, h->st));
+  }
+  std::vector<double> lh;
+  EvdInfo ei;
+  hermitian_evd(h->st, h->ews, Ap.r(), Ap.i(cplx), n, n, lh, nullptr, Zp.r(), Zp.i(cplx), n, &ei);
+  std::memcpy(lam, lh.data(), sizeof(double) * n);
+  if (info) { info[0] = ei.sweeps; info[1] = ei.tile; info[2] = ei.slots; }
+  if (Zh) {
+    const size_t no = nn * (cplx ? 2 : 1);
+    hipLaunchKernelGGL((pack_rows_kernel<double>), ew_grid((int64_t)nn), dim3(EW_BLOCK), 0, h->st, Zp.r(), Zp.i(cplx), (int64_t)n, n, n,
+                       zout.ensure(no), 0);
+    XMCA_HIP(hipGetLastError());
+    XMCA_HIP(hipMemcpyAsync(Zh, zout.get(), sizeof(double) * no, hipMemcpyDeviceToHost, h->st));
+    XMCA_HIP(hipStreamSynchronize(h->st));
+  }
+  API_END(h)
+}
+
+int xmca_bench_gram(xmca_handle* h, int side, int reps, double* avg_ms, double* kernel_ms, double* flops) {
+  API_BEGIN(h)
+  XMCA_CHECK((side == 0 || side == 1) && h->field_set[side] && reps >= 1, XMCA_ERR_STATE, "bench_gram: field not set");
+  hipEvent_t e0, e1;
+  XMCA_HIP(hipEventCreate(&e0));
+  XMCA_HIP(hipEventCreate(&e1));
+  int64_t T, N;
+  DevBuf<double> G;
+  auto run = [&](int force_splits, bool kernel_only, int n) {
+    GemmOpts o;
+    o.b_nfast = false; o.upper_only = true; o.mirror = 1; o.force_splits = force_splits;
+    (void)kernel_only;
+    for (int i = 0; i < n; ++i) {
+      if (h->dtype == XMCA_F32)
+        gemm<float, double>(h->st, h->gws, h->f32[side].r(), N, h->f32[side].r(), N, G.get(), T, (int)T, (int)T, (int)N, o);
+      else
+        gemm<double, double>(h->st, h->gws, h->f64[side].r(), N, h->f64[side].r(), N, G.get(), T, (int)T, (int)T, (int)N, o);
+    }
+  };
+  if (h->dtype == XMCA_F32) { T = h->f32[side].T; N = h->f32[side].N; } else { T = h->f64[side].T; N = h->f64[side].N; }
+  G.ensure((size_t)T * T);
+  run(0, false, 1);   // warm-up
+  XMCA_HIP(hipStreamSynchronize(h->st));
+  float ms = 0.f;
+  XMCA_HIP(hipEventRecord(e0, h->st));
+  run(0, false, reps);
+  XMCA_HIP(hipEventRecord(e1, h->st));
+  XMCA_HIP(hipEventSynchronize(e1));
+  XMCA_HIP(hipEventElapsedTime(&ms, e0, e1));
+  if (avg_ms) *avg_ms = ms / reps;
+  if (kernel_ms) *kernel_ms = ms / reps;
+  if (flops) *flops = (double)T * (double)(T + 1) * (double)N;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  API_END(h)
+}
+
+}  // extern "C"
