@@ -95,6 +95,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     stages = {k: v / args.steps for k, v in h.timings().items()}
+    stages["eigh_info"] = h.solve_info()[0]
     if td is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         td.all_reduce(tt, op=td.ReduceOp.MAX)
@@ -110,6 +111,14 @@ def main():
                 "traffic": None, "flops_per_launch": g["flops"], "avg_ms": g["avg_ms"]}
 
     extra = {}
+    # cheap self-check of the timed result (full parity against the oracle is in cpu_baseline/parity and tests/)
+    Vt = h.vectors(0, args.n_rot, N, X.dtype)
+    proj = X @ Vt.T
+    extra["self_check"] = {
+        "trace_identity_rel_err": float(abs(sig.sum() - (X * X).sum() / (T - 1)) / sig.sum()),
+        "rayleigh_rel_err_first_modes": float(np.max(np.abs((proj * proj).sum(axis=0) / (T - 1) - sig[:args.n_rot]) / sig[:args.n_rot])),
+        "orthonormality_first_modes": float(np.max(np.abs(Vt @ Vt.T - np.eye(args.n_rot)))),
+    }
     # ---- PCIe-inclusive end-to-end through the drop-in class (reported, never `value`) ----
     if rank == 0:
         t0 = time.perf_counter()

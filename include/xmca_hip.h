@@ -72,6 +72,9 @@ int xmca_get_singular_values(xmca_handle* h, double* out, int64_t n);
  * the model is complex.  dtype selects float32 / float64 components. */
 int xmca_get_vectors(xmca_handle* h, int side, void* out, int64_t n_modes, int dtype);
 int xmca_is_complex(xmca_handle* h);
+/* Diagnostics of the last solve: for each of the up to three eigen-decompositions (left Gram, right Gram, kernel):
+ * info[3*i + 0] = outer sweeps, info[3*i + 1] = tile size, info[3*i + 2] = pair slots.  n <= 9. */
+int xmca_get_solve_info(xmca_handle* h, int* info, int n);
 
 /* promax / varimax of xmca/tools/rotation.py:84-149, :15-78 on a host loading matrix L (N x p row-major,
  * float64, interleaved complex when is_complex), as built by MCA.rotate (array.py:821-822).

@@ -36,6 +36,7 @@ SIGNATURES = {
     "xmca_get_singular_values": (_c_int, [_vp, _vp, _c_i64]),
     "xmca_get_vectors": (_c_int, [_vp, _c_int, _vp, _c_i64, _c_int]),
     "xmca_is_complex": (_c_int, [_vp]),
+    "xmca_get_solve_info": (_c_int, [_vp, _vp, _c_int]),
     "xmca_rotate_loadings": (_c_int, [_vp, _vp, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_dbl, _c_int, _c_int,
                                       _vp, _vp, _vp, _vp, _vp, _ip]),
     "xmca_rule_n": (_c_int, [_vp, _c_i64, _c_i64, _c_i64, _c_int, _vp, _c_int, _c_int, _c_int, _c_dbl, _c_i64, _c_i64,
@@ -190,6 +191,11 @@ class Handle:
         rank = _c_i64(0)
         self._check(self._lib.xmca_solve(self._h, n_fields, n_vec, ctypes.byref(rank)))
         return int(rank.value)
+
+    def solve_info(self):
+        info = np.zeros(9, dtype=np.int32)
+        self._check(self._lib.xmca_get_solve_info(self._h, _ptr(info), 9))
+        return [{"sweeps": int(info[3 * i]), "tile": int(info[3 * i + 1]), "slots": int(info[3 * i + 2])} for i in range(3)]
 
     def singular_values(self, n):
         out = np.empty(n, dtype=np.float64)

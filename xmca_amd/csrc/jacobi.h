@@ -78,7 +78,7 @@ __global__ void jacobi_init_kernel(const double* __restrict__ Ar, const double* 
 template <int NT, bool CPLX>
 __global__ __launch_bounds__(256) void jacobi_tile_evd_kernel(const double* __restrict__ Gr, const double* __restrict__ Gi,
                                                               int ld, double* __restrict__ Jr, double* __restrict__ Ji,
-                                                              double* __restrict__ lam, double tol,
+                                                              double* __restrict__ Dr, double* __restrict__ Di, double tol,
                                                               const double* __restrict__ scal,
                                                               unsigned long long* __restrict__ sweep_off, int max_sweeps) {
   constexpr int H = NT / 2;
@@ -88,7 +88,6 @@ __global__ __launch_bounds__(256) void jacobi_tile_evd_kernel(const double* __re
   __shared__ double Vr[NT][LD];
   __shared__ double Vi[CPLX ? NT : 1][CPLX ? LD : 1];
   __shared__ double rc[H], rsr[H], rsi[H];
-  __shared__ int rp[H], rq[H];
   __shared__ int flag;
   __shared__ double red[4];
 
@@ -127,42 +126,58 @@ __global__ __launch_bounds__(256) void jacobi_tile_evd_kernel(const double* __re
     }
   }
 
+  // Parallel-order cyclic Jacobi.  Thread t owns, for the whole kernel, the column pair k2 = t % H (for the
+  // 2x2 blocks (k1, k2) it transforms and for the rows of V it rotates), so the rotation of k2 is read once per
+  // step and only the k1 rotations are re-read per block: ~3x fewer LDS operations than a generic item loop.
+  constexpr int KSTRIDE = 256 / H;            // 8 (NT = 64) or 16 (NT = 32)
+  constexpr int NBLK = (H * H) / 256;         // 2x2 blocks per thread: 4 or 1
+  constexpr int NROW = NT / KSTRIDE;          // rows of V per thread: 8 or 2
+  const int k2 = tid % H, kb = tid / H;
+  auto pair_of = [](int k, int step, int& p, int& q) {
+    int a, b;
+    if (k == 0) { a = NT - 1; b = step; }
+    else { a = step + k; if (a >= NT - 1) a -= NT - 1; b = step - k; if (b < 0) b += NT - 1; }
+    p = min(a, b); q = max(a, b);
+  };
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
     if (tid == 0) flag = 0;
     __syncthreads();
     for (int step = 0; step < NT - 1; ++step) {
       if (tid < H) {
-        int a, b;
-        if (tid == 0) { a = NT - 1; b = step; }
-        else { a = (step + tid) % (NT - 1); b = (step - tid + (NT - 1)) % (NT - 1); }
-        const int p = min(a, b), q = max(a, b);
+        int p, q;
+        pair_of(tid, step, p, q);
         const double app = Mr[p][p], aqq = Mr[q][q];
         const double gr = Mr[p][q];
         double gi = 0.0;
         if constexpr (CPLX) gi = Mi[p][q];
         const double g2 = gr * gr + gi * gi;
         double c = 1.0, sr = 0.0, si = 0.0;
-        if (g2 > 0.0 && g2 > abs_floor * abs_floor && g2 > tol * tol * fabs(app * aqq)) {
-          const double ag = sqrt(g2);
-          const double tau = (aqq - app) / (2.0 * ag);
-          const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-          c = 1.0 / sqrt(1.0 + t * t);
-          const double s = t * c;
-          sr = s * gr / ag;
-          si = s * gi / ag;
+        if (g2 > abs_floor * abs_floor && g2 > tol * tol * fabs(app * aqq)) {
+          // t = sign(d) 2|g| / (|d| + sqrt(d^2 + 4|g|^2)),  c = 1/sqrt(1+t^2),  s e^{i phi} = t c g/|g|
+          const double d = aqq - app;
+          const double inv = 1.0 / (fabs(d) + sqrt(d * d + 4.0 * g2));
+          const double w = (d >= 0.0 ? 2.0 : -2.0) * inv;       // t / |g|
+          c = 1.0 / sqrt(1.0 + w * w * g2);
+          sr = w * c * gr;
+          si = w * c * gi;
           flag = 1;
         }
-        rp[tid] = p; rq[tid] = q; rc[tid] = c; rsr[tid] = sr; rsi[tid] = si;
+        rc[tid] = c; rsr[tid] = sr; rsi[tid] = si;
       }
       __syncthreads();
+      int p2, q2;
+      pair_of(k2, step, p2, q2);
+      const double c2 = rc[k2], s2r = rsr[k2], s2i = CPLX ? rsi[k2] : 0.0;
+      const bool id2 = (c2 == 1.0 && s2r == 0.0 && s2i == 0.0);
       // M <- J^H M J as (NT/2)^2 independent 2x2 blocks
-      for (int e = tid; e < H * H; e += 256) {
-        const int k1 = e / H, k2 = e % H;
-        const int p1 = rp[k1], q1 = rq[k1], p2 = rp[k2], q2 = rq[k2];
-        const double c1 = rc[k1], s1r = rsr[k1], s1i = rsi[k1];
-        const double c2 = rc[k2], s2r = rsr[k2], s2i = rsi[k2];
-        if (c1 == 1.0 && c2 == 1.0 && s1r == 0.0 && s2r == 0.0 && s1i == 0.0 && s2i == 0.0) continue;
-        double b00r = Mr[p1][p2], b01r = Mr[p1][q2], b10r = Mr[q1][p2], b11r = Mr[q1][q2];
+#pragma unroll
+      for (int b = 0; b < NBLK; ++b) {
+        const int k1 = kb + KSTRIDE * b;
+        const double c1 = rc[k1], s1r = rsr[k1], s1i = CPLX ? rsi[k1] : 0.0;
+        if (id2 && c1 == 1.0 && s1r == 0.0 && s1i == 0.0) continue;
+        int p1, q1;
+        pair_of(k1, step, p1, q1);
+        const double b00r = Mr[p1][p2], b01r = Mr[p1][q2], b10r = Mr[q1][p2], b11r = Mr[q1][q2];
         if constexpr (!CPLX) {
           // rows: x0 = c1 b0 - s1 b1 ; x1 = s1 b0 + c1 b1
           const double x00 = c1 * b00r - s1r * b10r, x01 = c1 * b01r - s1r * b11r;
@@ -173,7 +188,7 @@ __global__ __launch_bounds__(256) void jacobi_tile_evd_kernel(const double* __re
           if (k1 == k2) { y01 = 0.0; y10 = 0.0; }
           Mr[p1][p2] = y00; Mr[p1][q2] = y01; Mr[q1][p2] = y10; Mr[q1][q2] = y11;
         } else {
-          double b00i = Mi[p1][p2], b01i = Mi[p1][q2], b10i = Mi[q1][p2], b11i = Mi[q1][q2];
+          const double b00i = Mi[p1][p2], b01i = Mi[p1][q2], b10i = Mi[q1][p2], b11i = Mi[q1][q2];
           // x0j = c1 b0j - sg1 b1j ; x1j = conj(sg1) b0j + c1 b1j        (sg = sr + i si)
           const double x00r = c1 * b00r - (s1r * b10r - s1i * b10i), x00i = c1 * b00i - (s1r * b10i + s1i * b10r);
           const double x01r = c1 * b01r - (s1r * b11r - s1i * b11i), x01i = c1 * b01i - (s1r * b11i + s1i * b11r);
@@ -189,23 +204,23 @@ __global__ __launch_bounds__(256) void jacobi_tile_evd_kernel(const double* __re
           Mi[p1][p2] = y00i; Mi[p1][q2] = y01i; Mi[q1][p2] = y10i; Mi[q1][q2] = y11i;
         }
       }
-      // V <- V J   (columns p,q of every row)
-      for (int e = tid; e < NT * H; e += 256) {
-        const int i = e / H, k = e % H;
-        const double c = rc[k], sr = rsr[k], si = rsi[k];
-        if (c == 1.0 && sr == 0.0 && si == 0.0) continue;
-        const int p = rp[k], q = rq[k];
-        const double vpr = Vr[i][p], vqr = Vr[i][q];
-        if constexpr (!CPLX) {
-          Vr[i][p] = c * vpr - sr * vqr;
-          Vr[i][q] = sr * vpr + c * vqr;
-        } else {
-          const double vpi = Vi[i][p], vqi = Vi[i][q];
-          // new_p = c vp - conj(sg) vq ; new_q = sg vp + c vq
-          Vr[i][p] = c * vpr - (sr * vqr + si * vqi);
-          Vi[i][p] = c * vpi - (sr * vqi - si * vqr);
-          Vr[i][q] = (sr * vpr - si * vpi) + c * vqr;
-          Vi[i][q] = (sr * vpi + si * vpr) + c * vqi;
+      // V <- V J   (columns p2, q2 of this thread's rows)
+      if (!id2) {
+#pragma unroll
+        for (int r = 0; r < NROW; ++r) {
+          const int i = kb + KSTRIDE * r;
+          const double vpr = Vr[i][p2], vqr = Vr[i][q2];
+          if constexpr (!CPLX) {
+            Vr[i][p2] = c2 * vpr - s2r * vqr;
+            Vr[i][q2] = s2r * vpr + c2 * vqr;
+          } else {
+            const double vpi = Vi[i][p2], vqi = Vi[i][q2];
+            // new_p = c vp - conj(sg) vq ; new_q = sg vp + c vq
+            Vr[i][p2] = c2 * vpr - (s2r * vqr + s2i * vqi);
+            Vi[i][p2] = c2 * vpi - (s2r * vqi - s2i * vqr);
+            Vr[i][q2] = (s2r * vpr - s2i * vpi) + c2 * vqr;
+            Vi[i][q2] = (s2r * vpi + s2i * vpr) + c2 * vqi;
+          }
         }
       }
       __syncthreads();
@@ -219,154 +234,233 @@ __global__ __launch_bounds__(256) void jacobi_tile_evd_kernel(const double* __re
   for (int e = tid; e < NT * NT; e += 256) {
     const int i = e / NT, j = e % NT;
     Jr[jb + e] = Vr[i][j];
-    if constexpr (CPLX) Ji[jb + e] = Vi[i][j];
+    Dr[jb + e] = Mr[i][j];          // J^H M J: diagonal only when the tile was swept to convergence
+    if constexpr (CPLX) { Ji[jb + e] = Vi[i][j]; Di[jb + e] = (i == j) ? 0.0 : Mi[i][j]; }
   }
-  if (tid < NT) lam[(int64_t)P * NT + tid] = Mr[tid][tid];
 }
 
-// One round of the two-sided update.  blockIdx.x enumerates the S(S+1)/2 upper G tiles, then the S*S Z tiles.
-template <int NT, bool CPLX>
-__global__ __launch_bounds__(256) void jacobi_update_kernel(const double* __restrict__ Gr_in, const double* __restrict__ Gi_in,
-                                                            double* __restrict__ Gr_out, double* __restrict__ Gi_out,
-                                                            const double* __restrict__ Zr_in, const double* __restrict__ Zi_in,
-                                                            double* __restrict__ Zr_out, double* __restrict__ Zi_out,
-                                                            const double* __restrict__ Jr, const double* __restrict__ Ji,
-                                                            const double* __restrict__ lam, int S, int ld) {
+// Which tiles of round r must exist before the diagonal tiles of round r+1 can be solved ("lookahead head"):
+// the new pair slot P' is made of one half of two different old slots (A, B); its off-diagonal quarter comes from
+// the updated tile (A, B).  With the tournament of jacobi_dest_block these are (0,1), (P,P+2) and (S-2,S-1).
+__host__ __device__ inline bool jacobi_is_next_diag(int P, int Q, int S) {
+  if (S <= 2) return true;
+  return (P == 0 && Q == 1) || (Q == P + 2) || (P == S - 2 && Q == S - 1);
+}
+__host__ __device__ inline void jacobi_next_diag_pair(int Pn, int S, int& A, int& B) {
+  if (S <= 2 || Pn == 0) { A = 0; B = 1; return; }
+  if (Pn == S - 1) { A = S - 2; B = S - 1; return; }
+  A = Pn - 1; B = Pn + 1;
+}
+
+constexpr int JAC_ZW = 4;   // eigenvector tiles (NT x NT) handled per workgroup, sharing one J_P
+
+// One round of the two-sided update:  G'[P,Q] = J_P^H G[P,Q] J_Q (upper tiles + mirrored write),
+// Z'[P,c] = J_P^H Z[P,c], both written to the slots of the next round.
+//   MODE 0: all tiles.   MODE 1: diagonal tiles + lookahead head.   MODE 2: everything else.
+// Two LDS buffers (J and tile) so that two workgroups fit a CU; results are staged through LDS and leave as
+// full 256-byte row segments (also the mirrored, transposed copy).
+template <int NT, bool CPLX, int MODE>
+__global__ __launch_bounds__(256, 2) void jacobi_update_kernel(const double* __restrict__ Gr_in, const double* __restrict__ Gi_in,
+                                                               double* __restrict__ Gr_out, double* __restrict__ Gi_out,
+                                                               const double* __restrict__ Zr_in, const double* __restrict__ Zi_in,
+                                                               double* __restrict__ Zr_out, double* __restrict__ Zi_out,
+                                                               const double* __restrict__ Jr, const double* __restrict__ Ji,
+                                                               const double* __restrict__ Dr, const double* __restrict__ Di,
+                                                               int S, int ld) {
   constexpr int LD = NT + 1;
   constexpr int HB = NT / 2;
   constexpr int TPD = NT / 16;          // MFMA tiles per dimension
   constexpr int NACC = TPD * TPD / 4;   // output tiles per wave
-  __shared__ double JPr[NT][LD], JQr[NT][LD], Tr[NT][LD];
-  __shared__ double JPi[CPLX ? NT : 1][CPLX ? LD : 1], JQi[CPLX ? NT : 1][CPLX ? LD : 1], Ti[CPLX ? NT : 1][CPLX ? LD : 1];
+  constexpr int EPT = NT * NT / 256;    // tile elements per thread
+  __shared__ double Ar[NT][LD], Br[NT][LD];
+  __shared__ double Ai[CPLX ? NT : 1][CPLX ? LD : 1], Bi[CPLX ? NT : 1][CPLX ? LD : 1];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
-  const int nG = S * (S + 1) / 2;
-  int id = blockIdx.x;
-  bool is_g = id < nG;
-  int P, Q;
-  if (is_g) {
-    P = 0;
-    int rem = id;
-    while (rem >= S - P) { rem -= S - P; ++P; }
-    Q = P + rem;
-  } else {
-    id -= nG;
-    P = id / S;
-    Q = id % S;   // column chunk of Z
+  const int n_off = S * (S - 1) / 2;
+  const int zchunks = (S + JAC_ZW - 1) / JAC_ZW;
+  int kind, P, Q;   // kind 0: diagonal tile, 1: off-diagonal G tile, 2: Z chunk
+  {
+    int id = blockIdx.x;
+    if (MODE == 1) {
+      if (id < S) { kind = 0; P = Q = id; }
+      else {
+        kind = 1;
+        jacobi_next_diag_pair(id - S, S, P, Q);
+        if (S <= 2 && id - S > 0) return;               // S == 2: both new slots need the same tile
+      }
+    } else {
+      int base = 0;
+      if (MODE == 0) {
+        if (id < S) { kind = 0; P = Q = id; }
+        base = S;
+      }
+      if (MODE == 2 || id >= base) {
+        id -= base;
+        if (id < n_off) {
+          kind = 1;
+          P = 0;
+          int rem = id;
+          while (rem >= S - 1 - P) { rem -= S - 1 - P; ++P; }
+          Q = P + 1 + rem;
+          if (MODE == 2 && jacobi_is_next_diag(P, Q, S)) return;
+        } else {
+          id -= n_off;
+          kind = 2;
+          P = id / zchunks;
+          Q = (id % zchunks) * JAC_ZW;
+        }
+      }
+    }
   }
 
-  if (is_g && P == Q) {
-    // the diagonal tile becomes diag(lam_P); write it (and zeros) to its destination blocks
+  if (kind == 0) {
+    // the diagonal tile was transformed by the tile solver itself (J_P^H G[P,P] J_P); move it to its destination blocks
     for (int e = tid; e < NT * NT; e += 256) {
       const int r = e / NT, c = e % NT;
       const int dr = jacobi_dest_block(P, r / HB, S) * HB + r % HB;
       const int dc = jacobi_dest_block(P, c / HB, S) * HB + c % HB;
       const int64_t o = (int64_t)dr * ld + dc;
-      Gr_out[o] = (r == c) ? lam[(int64_t)P * NT + r] : 0.0;
-      if constexpr (CPLX) Gi_out[o] = 0.0;
+      Gr_out[o] = Dr[(int64_t)P * NT * NT + e];
+      if constexpr (CPLX) Gi_out[o] = Di[(int64_t)P * NT * NT + e];
     }
     return;
   }
 
+  const bool is_g = (kind == 1);
+  const int64_t jpb = (int64_t)P * NT * NT, jqb = (int64_t)Q * NT * NT;
+  double jqr[EPT], jqi[CPLX ? EPT : 1];
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) {
+    const int e = tid + 256 * i;
+    Ar[e / NT][e % NT] = Jr[jpb + e];
+    if constexpr (CPLX) Ai[e / NT][e % NT] = Ji[jpb + e];
+    if (is_g) {
+      jqr[i] = Jr[jqb + e];
+      if constexpr (CPLX) jqi[i] = Ji[jqb + e];
+    }
+  }
   const double* __restrict__ Sr = is_g ? Gr_in : Zr_in;
   const double* __restrict__ Si = is_g ? Gi_in : Zi_in;
-  const int64_t tbase = (int64_t)P * NT * ld + (int64_t)Q * NT;
-  const int64_t jpb = (int64_t)P * NT * NT, jqb = (int64_t)Q * NT * NT;
-  for (int e = tid; e < NT * NT; e += 256) {
-    const int r = e / NT, c = e % NT;
-    Tr[r][c] = Sr[tbase + (int64_t)r * ld + c];
-    JPr[r][c] = Jr[jpb + e];
-    if (is_g) JQr[r][c] = Jr[jqb + e];
-    if constexpr (CPLX) {
-      Ti[r][c] = Si[tbase + (int64_t)r * ld + c];
-      JPi[r][c] = Ji[jpb + e];
-      if (is_g) JQi[r][c] = Ji[jqb + e];
-    }
-  }
-  __syncthreads();
+  const int nsub = is_g ? 1 : min(JAC_ZW, S - Q);
 
-  // X = J_P^H T
-  d4_t xr[NACC], xi[CPLX ? NACC : 1];
+  for (int sub = 0; sub < nsub; ++sub) {
+    const int Qc = Q + sub;
+    const int64_t tbase = (int64_t)P * NT * ld + (int64_t)Qc * NT;
 #pragma unroll
-  for (int a = 0; a < NACC; ++a) {
-    const int t = wave * NACC + a, ti = t / TPD, tj = t % TPD;
-    d4_t ar = {0, 0, 0, 0}, ai = {0, 0, 0, 0};
-    for (int k0 = 0; k0 < NT; k0 += 4) {
-      const int k = k0 + l4;
-      const double jr = JPr[k][ti * 16 + l15];
-      const double tr = Tr[k][tj * 16 + l15];
-      ar = Mfma<double>::mma(jr, tr, ar);
-      if constexpr (CPLX) {
-        const double ji = JPi[k][ti * 16 + l15];
-        const double tim = Ti[k][tj * 16 + l15];
-        ar = Mfma<double>::mma(ji, tim, ar);     // + JPi^T Ti
-        ai = Mfma<double>::mma(jr, tim, ai);     // + JPr^T Ti
-        ai = Mfma<double>::mma(-ji, tr, ai);     // - JPi^T Tr
-      }
+    for (int i = 0; i < EPT; ++i) {
+      const int e = tid + 256 * i, r = e / NT, c = e % NT;
+      Br[r][c] = Sr[tbase + (int64_t)r * ld + c];
+      if constexpr (CPLX) Bi[r][c] = Si[tbase + (int64_t)r * ld + c];
     }
-    xr[a] = ar;
-    if constexpr (CPLX) xi[a] = ai;
-  }
+    __syncthreads();
 
-  if (!is_g) {
-    // Z'[dest(P,h) rows, chunk Q] = X
+    // X = J_P^H T
+    d4_t xr[NACC], xi[CPLX ? NACC : 1];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) {
+      const int t = wave * NACC + a, ti = t / TPD, tj = t % TPD;
+      d4_t ar = {0, 0, 0, 0}, ai = {0, 0, 0, 0};
+#pragma unroll 4
+      for (int k0 = 0; k0 < NT; k0 += 4) {
+        const int k = k0 + l4;
+        const double jr = Ar[k][ti * 16 + l15];
+        const double tr = Br[k][tj * 16 + l15];
+        ar = Mfma<double>::mma(jr, tr, ar);
+        if constexpr (CPLX) {
+          const double ji = Ai[k][ti * 16 + l15];
+          const double tim = Bi[k][tj * 16 + l15];
+          ar = Mfma<double>::mma(ji, tim, ar);     // + JPi^T Ti
+          ai = Mfma<double>::mma(jr, tim, ai);     // + JPr^T Ti
+          ai = Mfma<double>::mma(-ji, tr, ai);     // - JPi^T Tr
+        }
+      }
+      xr[a] = ar;
+      if constexpr (CPLX) xi[a] = ai;
+    }
+    __syncthreads();   // every wave is done reading the tile (and J_P when this is a G tile)
 #pragma unroll
     for (int a = 0; a < NACC; ++a) {
       const int t = wave * NACC + a, ti = t / TPD, tj = t % TPD;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = ti * 16 + Mfma<double>::row(lane, r), col = tj * 16 + l15;
-        const int dr = jacobi_dest_block(P, row / HB, S) * HB + row % HB;
-        const int64_t o = (int64_t)dr * ld + (int64_t)Q * NT + col;
-        Zr_out[o] = xr[a][r];
-        if constexpr (CPLX) Zi_out[o] = xi[a][r];
+        Br[row][col] = xr[a][r];
+        if constexpr (CPLX) Bi[row][col] = xi[a][r];
       }
     }
-    return;
-  }
+    if (is_g) {
+#pragma unroll
+      for (int i = 0; i < EPT; ++i) {
+        const int e = tid + 256 * i;
+        Ar[e / NT][e % NT] = jqr[i];
+        if constexpr (CPLX) Ai[e / NT][e % NT] = jqi[i];
+      }
+    }
+    __syncthreads();
 
-  __syncthreads();   // every wave is done reading T
+    if (!is_g) {
+      // Z'[dest(P,h) rows, chunk Qc] = X   (row segments of NT doubles)
 #pragma unroll
-  for (int a = 0; a < NACC; ++a) {
-    const int t = wave * NACC + a, ti = t / TPD, tj = t % TPD;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = ti * 16 + Mfma<double>::row(lane, r), col = tj * 16 + l15;
-      Tr[row][col] = xr[a][r];
-      if constexpr (CPLX) Ti[row][col] = xi[a][r];
+      for (int i = 0; i < EPT; ++i) {
+        const int e = tid + 256 * i, r = e / NT, c = e % NT;
+        const int dr = jacobi_dest_block(P, r / HB, S) * HB + r % HB;
+        const int64_t o = (int64_t)dr * ld + (int64_t)Qc * NT + c;
+        Zr_out[o] = Br[r][c];
+        if constexpr (CPLX) Zi_out[o] = Bi[r][c];
+      }
+      __syncthreads();   // the next sub-tile overwrites B
+      continue;
     }
-  }
-  __syncthreads();
 
-  // Y = X J_Q, scattered to the next round's slots (+ Hermitian mirror)
+    // Y = X J_Q
+    d4_t yr[NACC], yi[CPLX ? NACC : 1];
 #pragma unroll
-  for (int a = 0; a < NACC; ++a) {
-    const int t = wave * NACC + a, ti = t / TPD, tj = t % TPD;
-    d4_t yr = {0, 0, 0, 0}, yi = {0, 0, 0, 0};
-    for (int k0 = 0; k0 < NT; k0 += 4) {
-      const int k = k0 + l4;
-      const double xre = Tr[ti * 16 + l15][k];
-      const double qr = JQr[k][tj * 16 + l15];
-      yr = Mfma<double>::mma(xre, qr, yr);
-      if constexpr (CPLX) {
-        const double xim = Ti[ti * 16 + l15][k];
-        const double qi = JQi[k][tj * 16 + l15];
-        yr = Mfma<double>::mma(-xim, qi, yr);
-        yi = Mfma<double>::mma(xre, qi, yi);
-        yi = Mfma<double>::mma(xim, qr, yi);
+    for (int a = 0; a < NACC; ++a) {
+      const int t = wave * NACC + a, ti = t / TPD, tj = t % TPD;
+      d4_t ar = {0, 0, 0, 0}, ai = {0, 0, 0, 0};
+#pragma unroll 4
+      for (int k0 = 0; k0 < NT; k0 += 4) {
+        const int k = k0 + l4;
+        const double xre = Br[ti * 16 + l15][k];
+        const double qr = Ar[k][tj * 16 + l15];
+        ar = Mfma<double>::mma(xre, qr, ar);
+        if constexpr (CPLX) {
+          const double xim = Bi[ti * 16 + l15][k];
+          const double qi = Ai[k][tj * 16 + l15];
+          ar = Mfma<double>::mma(-xim, qi, ar);
+          ai = Mfma<double>::mma(xre, qi, ai);
+          ai = Mfma<double>::mma(xim, qr, ai);
+        }
+      }
+      yr[a] = ar;
+      if constexpr (CPLX) yi[a] = ai;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) {
+      const int t = wave * NACC + a, ti = t / TPD, tj = t % TPD;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = ti * 16 + Mfma<double>::row(lane, r), col = tj * 16 + l15;
+        Br[row][col] = yr[a][r];
+        if constexpr (CPLX) Bi[row][col] = yi[a][r];
       }
     }
+    __syncthreads();
+    // scatter to the next round's slots: the tile itself (rows) and its Hermitian mirror (columns read from LDS)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = ti * 16 + Mfma<double>::row(lane, r), col = tj * 16 + l15;
-      const int dr = jacobi_dest_block(P, row / HB, S) * HB + row % HB;
-      const int dc = jacobi_dest_block(Q, col / HB, S) * HB + col % HB;
-      Gr_out[(int64_t)dr * ld + dc] = yr[r];
-      Gr_out[(int64_t)dc * ld + dr] = yr[r];
-      if constexpr (CPLX) {
-        Gi_out[(int64_t)dr * ld + dc] = yi[r];
-        Gi_out[(int64_t)dc * ld + dr] = -yi[r];
-      }
+    for (int i = 0; i < EPT; ++i) {
+      const int e = tid + 256 * i, r = e / NT, c = e % NT;
+      const int dr = jacobi_dest_block(P, r / HB, S) * HB + r % HB;
+      const int dc = jacobi_dest_block(Q, c / HB, S) * HB + c % HB;
+      Gr_out[(int64_t)dr * ld + dc] = Br[r][c];
+      if constexpr (CPLX) Gi_out[(int64_t)dr * ld + dc] = Bi[r][c];
+      // mirrored element: this thread now plays (row' = c-index, col' = r-index) with r fastest
+      const int r2 = e % NT, c2 = e / NT;
+      const int dr2 = jacobi_dest_block(P, r2 / HB, S) * HB + r2 % HB;
+      const int dc2 = jacobi_dest_block(Q, c2 / HB, S) * HB + c2 % HB;
+      Gr_out[(int64_t)dc2 * ld + dr2] = Br[r2][c2];
+      if constexpr (CPLX) Gi_out[(int64_t)dc2 * ld + dr2] = -Bi[r2][c2];
     }
   }
 }
@@ -390,9 +484,28 @@ __global__ void jacobi_gather_kernel(const double* __restrict__ Zr, const double
 
 struct EvdWorkspace {
   DevBuf<double> G[2][2], Z[2][2];  // [ping-pong][plane]
-  DevBuf<double> J[2], lam, diag, scal;
-  DevBuf<unsigned long long> off;
+  DevBuf<double> J[2][2], D[2][2];  // [round parity][plane]: rotations J_P and transformed diagonal tiles; the lookahead
+                                    // solve of round r+1 writes one parity while round r reads the other
+  DevBuf<double> diag, scal;
+  DevBuf<unsigned long long> off;   // one accumulator per sweep (ring)
   DevBuf<int> perm;
+  hipStream_t aux = nullptr;        // second stream: diagonal-tile solves of the NEXT round
+  hipEvent_t ev_head[4] = {nullptr, nullptr, nullptr, nullptr}, ev_evd[4] = {nullptr, nullptr, nullptr, nullptr};
+  ~EvdWorkspace() {
+    for (int i = 0; i < 4; ++i) {
+      if (ev_head[i]) (void)hipEventDestroy(ev_head[i]);
+      if (ev_evd[i]) (void)hipEventDestroy(ev_evd[i]);
+    }
+    if (aux) (void)hipStreamDestroy(aux);
+  }
+  void init_streams() {
+    if (aux) return;
+    XMCA_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+    for (int i = 0; i < 4; ++i) {
+      XMCA_HIP(hipEventCreateWithFlags(&ev_head[i], hipEventDisableTiming));
+      XMCA_HIP(hipEventCreateWithFlags(&ev_evd[i], hipEventDisableTiming));
+    }
+  }
 };
 
 struct EvdInfo {
@@ -402,73 +515,98 @@ struct EvdInfo {
   double last_off = 0.0;
 };
 
+constexpr int JAC_OFF_RING = 64;
+
 // Hermitian EVD  A = U diag(lam) U^H, lam descending.
 //   Ar/Ai : n x n row-major planes (Ai == nullptr for a real symmetric matrix), lda
 //   lam_host : n eigenvalues (descending); lam_dev (nullable) gets the same on the device
 //   Zr/Zi : n x n, row i = conj(u_i)   (ldz)
-template <bool CPLX>
+template <bool CPLX, int NT>
 void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, const double* Ai, int n, int64_t lda,
-                        std::vector<double>& lam_host, double* lam_dev, double* Zr, double* Zi, int64_t ldz, int nt,
-                        double tol, int max_sweeps, EvdInfo* info) {
-  const int NT = nt;
+                        std::vector<double>& lam_host, double* lam_dev, double* Zr, double* Zi, int64_t ldz, double tol,
+                        int max_sweeps, EvdInfo* info) {
   const int S = std::max(ceil_div(n, NT), 1);
   const int npad = S * NT;
   const size_t nn = (size_t)npad * npad;
+  ws.init_streams();
   for (int b = 0; b < 2; ++b) {
     ws.G[b][0].ensure(nn);
     ws.Z[b][0].ensure(nn);
-    if (CPLX) { ws.G[b][1].ensure(nn); ws.Z[b][1].ensure(nn); }
+    ws.J[b][0].ensure((size_t)S * NT * NT);
+    ws.D[b][0].ensure((size_t)S * NT * NT);
+    if (CPLX) { ws.G[b][1].ensure(nn); ws.Z[b][1].ensure(nn); ws.J[b][1].ensure((size_t)S * NT * NT); ws.D[b][1].ensure((size_t)S * NT * NT); }
   }
-  ws.J[0].ensure((size_t)S * NT * NT);
-  if (CPLX) ws.J[1].ensure((size_t)S * NT * NT);
-  ws.lam.ensure((size_t)npad);
   ws.diag.ensure((size_t)npad);
   ws.scal.ensure(2);
-  ws.off.ensure(1);
+  ws.off.ensure(JAC_OFF_RING);
   ws.perm.ensure((size_t)npad);
+  if (max_sweeps > JAC_OFF_RING - 1) max_sweeps = JAC_OFF_RING - 1;
 
+  XMCA_HIP(hipMemsetAsync(ws.off.get(), 0, sizeof(unsigned long long) * JAC_OFF_RING, st));
   hipLaunchKernelGGL(jacobi_init_scale_kernel, dim3(1), dim3(256), 0, st, Ar, n, lda, tol, ws.scal.get());
   hipLaunchKernelGGL(jacobi_init_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, Ar, CPLX ? Ai : nullptr, n, lda,
                      ws.G[0][0].get(), CPLX ? ws.G[0][1].get() : nullptr, ws.Z[0][0].get(), CPLX ? ws.Z[0][1].get() : nullptr,
                      npad, ws.scal.get());
   XMCA_HIP(hipGetLastError());
 
+  const double tile_tol = 2e-15;
+  // Inexact inner solves: a diagonal tile is swept only `inner_cap` times per visit.  Measured on MI355X (C2,
+  // T = 2920): 1 sweep per visit needs the same 13 outer sweeps as a full tile solve at a third of the time.
+  static const int inner_cap = [] { const char* e = std::getenv("XMCA_JACOBI_INNER"); int v = e ? std::atoi(e) : 0; return v > 0 ? v : 1; }();
+  static const bool lookahead_on = [] { const char* e = std::getenv("XMCA_JACOBI_LOOKAHEAD"); return !(e && e[0] == '0'); }();
+  const bool lookahead = lookahead_on && S >= 3;
+
   int cur = 0;
   const int rounds = (S == 1) ? 1 : 2 * S - 1;
-  const int n_tiles = S * (S + 1) / 2 + S * S;
-  int sweeps = 0;
-  double off = 0.0;
-  const double tile_tol = 2e-15;
-  auto launch_round = [&](auto nt_tag) {
-    constexpr int NTC = decltype(nt_tag)::value;
-    hipLaunchKernelGGL((jacobi_tile_evd_kernel<NTC, CPLX>), dim3(S), dim3(256), 0, st, ws.G[cur][0].get(),
-                       CPLX ? ws.G[cur][1].get() : nullptr, npad, ws.J[0].get(), CPLX ? ws.J[1].get() : nullptr,
-                       ws.lam.get(), tile_tol, ws.scal.get(), ws.off.get(), S == 1 ? 60 : 30);
-    hipLaunchKernelGGL((jacobi_update_kernel<NTC, CPLX>), dim3(n_tiles), dim3(256), 0, st, ws.G[cur][0].get(),
+  const int zchunks = (S + JAC_ZW - 1) / JAC_ZW;
+  const int n_off = S * (S - 1) / 2;
+  auto evd = [&](hipStream_t s, int gbuf, int par, int sweep_slot) {
+    hipLaunchKernelGGL((jacobi_tile_evd_kernel<NT, CPLX>), dim3(S), dim3(256), 0, s, ws.G[gbuf][0].get(),
+                       CPLX ? ws.G[gbuf][1].get() : nullptr, npad, ws.J[par][0].get(), CPLX ? ws.J[par][1].get() : nullptr,
+                       ws.D[par][0].get(), CPLX ? ws.D[par][1].get() : nullptr, tile_tol, ws.scal.get(),
+                       ws.off.get() + sweep_slot, S == 1 ? 60 : inner_cap);
+  };
+  auto update = [&](auto mode_tag, hipStream_t s, int par, int grid) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    hipLaunchKernelGGL((jacobi_update_kernel<NT, CPLX, MODE>), dim3(grid), dim3(256), 0, s, ws.G[cur][0].get(),
                        CPLX ? ws.G[cur][1].get() : nullptr, ws.G[cur ^ 1][0].get(), CPLX ? ws.G[cur ^ 1][1].get() : nullptr,
                        ws.Z[cur][0].get(), CPLX ? ws.Z[cur][1].get() : nullptr, ws.Z[cur ^ 1][0].get(),
-                       CPLX ? ws.Z[cur ^ 1][1].get() : nullptr, ws.J[0].get(), CPLX ? ws.J[1].get() : nullptr, ws.lam.get(),
-                       S, npad);
+                       CPLX ? ws.Z[cur ^ 1][1].get() : nullptr, ws.J[par][0].get(), CPLX ? ws.J[par][1].get() : nullptr,
+                       ws.D[par][0].get(), CPLX ? ws.D[par][1].get() : nullptr, S, npad);
   };
+
+  int sweeps = 0;
+  double off = 0.0;
+  int64_t round_no = 0;
+  if (lookahead) evd(st, cur, 0, 0);     // diagonal tiles of the very first round
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
-    XMCA_HIP(hipMemsetAsync(ws.off.get(), 0, sizeof(unsigned long long), st));
-    for (int r = 0; r < rounds; ++r) {
-      if constexpr (CPLX) {
-        launch_round(std::integral_constant<int, 32>{});   // 64x64 complex tiles do not fit the LDS of the update kernel
+    for (int r = 0; r < rounds; ++r, ++round_no) {
+      const int par = (int)(round_no & 1), er = (int)(round_no & 3);
+      if (!lookahead) {
+        evd(st, cur, par, sweep);
+        update(std::integral_constant<int, 0>{}, st, par, S + n_off + S * zchunks);
       } else {
-        if (NT == 32) launch_round(std::integral_constant<int, 32>{});
-        else launch_round(std::integral_constant<int, 64>{});
+        // head of round r on the main stream; the solve of round r+1 overlaps the bulk of round r
+        update(std::integral_constant<int, 1>{}, st, par, 2 * S);
+        XMCA_HIP(hipEventRecord(ws.ev_head[er], st));
+        XMCA_HIP(hipStreamWaitEvent(ws.aux, ws.ev_head[er], 0));
+        const int next_slot = (r == rounds - 1) ? sweep + 1 : sweep;
+        evd(ws.aux, cur ^ 1, par ^ 1, next_slot);
+        XMCA_HIP(hipEventRecord(ws.ev_evd[er], ws.aux));
+        update(std::integral_constant<int, 2>{}, st, par, n_off + S * zchunks);
+        XMCA_HIP(hipStreamWaitEvent(st, ws.ev_evd[er], 0));
       }
       cur ^= 1;
     }
     XMCA_HIP(hipGetLastError());
     unsigned long long bits = 0;
-    XMCA_HIP(hipMemcpyAsync(&bits, ws.off.get(), sizeof(bits), hipMemcpyDeviceToHost, st));
+    XMCA_HIP(hipMemcpyAsync(&bits, ws.off.get() + sweep, sizeof(bits), hipMemcpyDeviceToHost, st));
     XMCA_HIP(hipStreamSynchronize(st));
     std::memcpy(&off, &bits, sizeof(double));
     ++sweeps;
     if (S == 1 || !(off >= tol) || !std::isfinite(off)) break;
   }
+  XMCA_HIP(hipStreamSynchronize(ws.aux));
   XMCA_CHECK(std::isfinite(off), XMCA_ERR_NUMERIC, "SVD failed. NaN entries may be the problem.");
 
   // eigenvalues = diagonal; sort descending on the host, drop the padding (= the most negative entries)
@@ -499,12 +637,14 @@ inline void hermitian_evd(hipStream_t st, EvdWorkspace& ws, const double* Ar, co
   // 1e-10 * max|diag|: with the (at least fast-linear, normally quadratic) convergence the state left
   // behind is at the 1e-13 rotation floor.
   const double tol = 1e-10;
-  const int max_sweeps = 40;
+  const int max_sweeps = 50;
   if (Ai) {
-    hermitian_evd_impl<true>(st, ws, Ar, Ai, n, lda, lam_host, lam_dev, Zr, Zi, ldz, 32, tol, max_sweeps, info);
+    // 64 x 64 complex tiles do not fit the LDS of the update kernel
+    hermitian_evd_impl<true, 32>(st, ws, Ar, Ai, n, lda, lam_host, lam_dev, Zr, Zi, ldz, tol, max_sweeps, info);
   } else {
-    int nt = force_tile ? force_tile : (n > 32 ? 64 : 32);
-    hermitian_evd_impl<false>(st, ws, Ar, nullptr, n, lda, lam_host, lam_dev, Zr, nullptr, ldz, nt, tol, max_sweeps, info);
+    const int nt = force_tile ? force_tile : (n > 32 ? 64 : 32);
+    if (nt == 32) hermitian_evd_impl<false, 32>(st, ws, Ar, nullptr, n, lda, lam_host, lam_dev, Zr, nullptr, ldz, tol, max_sweeps, info);
+    else hermitian_evd_impl<false, 64>(st, ws, Ar, nullptr, n, lda, lam_host, lam_dev, Zr, nullptr, ldz, tol, max_sweeps, info);
   }
 }
 

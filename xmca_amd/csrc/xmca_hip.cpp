@@ -309,6 +309,15 @@ int xmca_get_singular_values(xmca_handle* h, double* out, int64_t n) {
 
 int xmca_is_complex(xmca_handle* h) { return (h && h->solved && h->res.cplx) ? 1 : 0; }
 
+int xmca_get_solve_info(xmca_handle* h, int* info, int n) {
+  if (!h || !info) return XMCA_ERR_INVALID;
+  for (int i = 0; i < n && i < 9; ++i) {
+    const EvdInfo& e = h->res.evd_info[i / 3];
+    info[i] = (i % 3 == 0) ? e.sweeps : (i % 3 == 1) ? e.tile : e.slots;
+  }
+  return XMCA_OK;
+}
+
 int xmca_get_vectors(xmca_handle* h, int side, void* out, int64_t n_modes, int dtype) {
   API_BEGIN(h)
   XMCA_CHECK(h->solved, XMCA_ERR_STATE, "vectors requested before solve");
