@@ -75,23 +75,43 @@ __global__ void jacobi_init_kernel(const double* __restrict__ Ar, const double* 
   if (Gi) { Gi[idx] = gi; Zi[idx] = 0.0; }
 }
 
+// LDS images of the two kernel bodies (a fused launch runs both kinds of workgroups, so they share one union)
 template <int NT, bool CPLX>
-__global__ __launch_bounds__(256) void jacobi_tile_evd_kernel(const double* __restrict__ Gr, const double* __restrict__ Gi,
-                                                              int ld, double* __restrict__ Jr, double* __restrict__ Ji,
-                                                              double* __restrict__ Dr, double* __restrict__ Di, double tol,
-                                                              const double* __restrict__ scal,
-                                                              unsigned long long* __restrict__ sweep_off, int max_sweeps) {
+struct JacTileSmem {
+  double Mr[NT][NT + 1];
+  double Vr[NT][NT + 1];
+  double Mi[CPLX ? NT : 1][CPLX ? NT + 1 : 1];
+  double Vi[CPLX ? NT : 1][CPLX ? NT + 1 : 1];
+  double rc[NT / 2], rsr[NT / 2], rsi[NT / 2];
+  double red[4];
+  int flag;
+};
+template <int NT, bool CPLX>
+struct JacUpdSmem {
+  double Ar[NT][NT + 1], Br[NT][NT + 1];
+  double Ai[CPLX ? NT : 1][CPLX ? NT + 1 : 1], Bi[CPLX ? NT : 1][CPLX ? NT + 1 : 1];
+};
+
+template <int NT, bool CPLX>
+__device__ __forceinline__ void jacobi_tile_evd_body(JacTileSmem<NT, CPLX>& sm, const int P, const double* __restrict__ Gr,
+                                                     const double* __restrict__ Gi, int ld, double* __restrict__ Jr,
+                                                     double* __restrict__ Ji, double* __restrict__ Dr, double* __restrict__ Di,
+                                                     double tol, const double* __restrict__ scal,
+                                                     unsigned long long* __restrict__ sweep_off, int max_sweeps,
+                                                     const bool cross_only) {
   constexpr int H = NT / 2;
   constexpr int LD = NT + 1;
-  __shared__ double Mr[NT][LD];
-  __shared__ double Mi[CPLX ? NT : 1][CPLX ? LD : 1];
-  __shared__ double Vr[NT][LD];
-  __shared__ double Vi[CPLX ? NT : 1][CPLX ? LD : 1];
-  __shared__ double rc[H], rsr[H], rsi[H];
-  __shared__ int flag;
-  __shared__ double red[4];
+  auto& Mr = sm.Mr;
+  auto& Mi = sm.Mi;
+  auto& Vr = sm.Vr;
+  auto& Vi = sm.Vi;
+  auto& rc = sm.rc;
+  auto& rsr = sm.rsr;
+  auto& rsi = sm.rsi;
+  auto& red = sm.red;
+  int& flag = sm.flag;
 
-  const int P = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   const double gscale = scal[0], abs_floor = scal[1];
   const int64_t base = (int64_t)P * NT * ld + (int64_t)P * NT;
   for (int e = tid; e < NT * NT; e += 256) {
@@ -133,16 +153,28 @@ __global__ __launch_bounds__(256) void jacobi_tile_evd_kernel(const double* __re
   constexpr int NBLK = (H * H) / 256;         // 2x2 blocks per thread: 4 or 1
   constexpr int NROW = NT / KSTRIDE;          // rows of V per thread: 8 or 2
   const int k2 = tid % H, kb = tid / H;
-  auto pair_of = [](int k, int step, int& p, int& q) {
+  // full mode: round-robin tournament over all NT indices (NT-1 steps).  cross mode: only the pairs (p, q) with p in
+  // the first and q in the second half-block (NT/2 steps of cyclic shifts): the pairs inside a half-block have been
+  // rotated when that half-block was last swept in full mode and need it only once per outer sweep.
+  auto pair_of = [cross_only](int k, int step, int& p, int& q) {
+    if (cross_only) {
+      p = k;
+      int j = k + step;
+      if (j >= H) j -= H;
+      q = H + j;
+      return;
+    }
     int a, b;
     if (k == 0) { a = NT - 1; b = step; }
     else { a = step + k; if (a >= NT - 1) a -= NT - 1; b = step - k; if (b < 0) b += NT - 1; }
     p = min(a, b); q = max(a, b);
   };
+  const int n_steps = cross_only ? H : NT - 1;
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: when sharing a CU with MFMA-bound update workgroups, issue first
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
     if (tid == 0) flag = 0;
     __syncthreads();
-    for (int step = 0; step < NT - 1; ++step) {
+    for (int step = 0; step < n_steps; ++step) {
       if (tid < H) {
         int p, q;
         pair_of(tid, step, p, q);
@@ -260,27 +292,29 @@ constexpr int JAC_ZW = 4;   // eigenvector tiles (NT x NT) handled per workgroup
 // Two LDS buffers (J and tile) so that two workgroups fit a CU; results are staged through LDS and leave as
 // full 256-byte row segments (also the mirrored, transposed copy).
 template <int NT, bool CPLX, int MODE>
-__global__ __launch_bounds__(256, 2) void jacobi_update_kernel(const double* __restrict__ Gr_in, const double* __restrict__ Gi_in,
-                                                               double* __restrict__ Gr_out, double* __restrict__ Gi_out,
-                                                               const double* __restrict__ Zr_in, const double* __restrict__ Zi_in,
-                                                               double* __restrict__ Zr_out, double* __restrict__ Zi_out,
-                                                               const double* __restrict__ Jr, const double* __restrict__ Ji,
-                                                               const double* __restrict__ Dr, const double* __restrict__ Di,
-                                                               int S, int ld) {
+__device__ __forceinline__ void jacobi_update_body(JacUpdSmem<NT, CPLX>& sm, const int block_id, const double* __restrict__ Gr_in,
+                                                   const double* __restrict__ Gi_in, double* __restrict__ Gr_out,
+                                                   double* __restrict__ Gi_out, const double* __restrict__ Zr_in,
+                                                   const double* __restrict__ Zi_in, double* __restrict__ Zr_out,
+                                                   double* __restrict__ Zi_out, const double* __restrict__ Jr,
+                                                   const double* __restrict__ Ji, const double* __restrict__ Dr,
+                                                   const double* __restrict__ Di, int S, int ld) {
   constexpr int LD = NT + 1;
   constexpr int HB = NT / 2;
   constexpr int TPD = NT / 16;          // MFMA tiles per dimension
   constexpr int NACC = TPD * TPD / 4;   // output tiles per wave
   constexpr int EPT = NT * NT / 256;    // tile elements per thread
-  __shared__ double Ar[NT][LD], Br[NT][LD];
-  __shared__ double Ai[CPLX ? NT : 1][CPLX ? LD : 1], Bi[CPLX ? NT : 1][CPLX ? LD : 1];
+  auto& Ar = sm.Ar;
+  auto& Br = sm.Br;
+  auto& Ai = sm.Ai;
+  auto& Bi = sm.Bi;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
   const int n_off = S * (S - 1) / 2;
   const int zchunks = (S + JAC_ZW - 1) / JAC_ZW;
   int kind, P, Q;   // kind 0: diagonal tile, 1: off-diagonal G tile, 2: Z chunk
   {
-    int id = blockIdx.x;
+    int id = block_id;
     if (MODE == 1) {
       if (id < S) { kind = 0; P = Q = id; }
       else {
@@ -465,6 +499,49 @@ __global__ __launch_bounds__(256, 2) void jacobi_update_kernel(const double* __r
   }
 }
 
+template <int NT, bool CPLX>
+__global__ __launch_bounds__(256, 2) void jacobi_tile_evd_kernel(const double* Gr, const double* Gi, int ld, double* Jr, double* Ji,
+                                                                 double* Dr, double* Di, double tol, const double* scal,
+                                                                 unsigned long long* sweep_off, int max_sweeps, int cross_only) {
+  __shared__ JacTileSmem<NT, CPLX> sm;
+  jacobi_tile_evd_body<NT, CPLX>(sm, blockIdx.x, Gr, Gi, ld, Jr, Ji, Dr, Di, tol, scal, sweep_off, max_sweeps, cross_only != 0);
+}
+
+template <int NT, bool CPLX, int MODE>
+__global__ __launch_bounds__(256, 2) void jacobi_update_kernel(const double* Gr_in, const double* Gi_in, double* Gr_out,
+                                                               double* Gi_out, const double* Zr_in, const double* Zi_in,
+                                                               double* Zr_out, double* Zi_out, const double* Jr, const double* Ji,
+                                                               const double* Dr, const double* Di, int S, int ld) {
+  __shared__ JacUpdSmem<NT, CPLX> sm;
+  jacobi_update_body<NT, CPLX, MODE>(sm, blockIdx.x, Gr_in, Gi_in, Gr_out, Gi_out, Zr_in, Zi_in, Zr_out, Zi_out, Jr, Ji, Dr, Di, S,
+                                     ld);
+}
+
+// Fused launch of one round: the first S workgroups solve the diagonal tiles of round r+1 (already written by the
+// MODE 1 "head" launch of round r), all others run the bulk (MODE 2) of round r's update.  Low block ids are
+// dispatched first, so the latency-bound tile solves start at once and hide behind the MFMA-bound update tiles.
+template <int NT, bool CPLX>
+__global__ __launch_bounds__(256, 2) void jacobi_fused_round_kernel(const double* Gr_in, const double* Gi_in, double* Gr_out,
+                                                                    double* Gi_out, const double* Zr_in, const double* Zi_in,
+                                                                    double* Zr_out, double* Zi_out, const double* Jr,
+                                                                    const double* Ji, const double* Dr, const double* Di,
+                                                                    double* Jr_next, double* Ji_next, double* Dr_next,
+                                                                    double* Di_next, double tol, const double* scal,
+                                                                    unsigned long long* sweep_off, int max_sweeps, int cross_only,
+                                                                    int S, int ld) {
+  __shared__ union U {
+    JacTileSmem<NT, CPLX> t;
+    JacUpdSmem<NT, CPLX> u;
+    __device__ U() {}
+  } sm;
+  if ((int)blockIdx.x < S)
+    jacobi_tile_evd_body<NT, CPLX>(sm.t, blockIdx.x, Gr_out, Gi_out, ld, Jr_next, Ji_next, Dr_next, Di_next, tol, scal, sweep_off,
+                                   max_sweeps, cross_only != 0);
+  else
+    jacobi_update_body<NT, CPLX, 2>(sm.u, (int)blockIdx.x - S, Gr_in, Gi_in, Gr_out, Gi_out, Zr_in, Zi_in, Zr_out, Zi_out, Jr, Ji,
+                                    Dr, Di, S, ld);
+}
+
 __global__ void jacobi_diag_kernel(const double* __restrict__ Gr, int npad, double* __restrict__ d) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < npad) d[i] = Gr[(int64_t)i * npad + i];
@@ -500,7 +577,10 @@ struct EvdWorkspace {
   }
   void init_streams() {
     if (aux) return;
-    XMCA_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+    // highest priority: the 46-odd workgroups of a diagonal-tile solve must not queue behind the ~3000 of the update
+    int lo = 0, hi = 0;
+    XMCA_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    XMCA_HIP(hipStreamCreateWithPriority(&aux, hipStreamNonBlocking, hi));
     for (int i = 0; i < 4; ++i) {
       XMCA_HIP(hipEventCreateWithFlags(&ev_head[i], hipEventDisableTiming));
       XMCA_HIP(hipEventCreateWithFlags(&ev_evd[i], hipEventDisableTiming));
@@ -528,7 +608,6 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
   const int S = std::max(ceil_div(n, NT), 1);
   const int npad = S * NT;
   const size_t nn = (size_t)npad * npad;
-  ws.init_streams();
   for (int b = 0; b < 2; ++b) {
     ws.G[b][0].ensure(nn);
     ws.Z[b][0].ensure(nn);
@@ -560,11 +639,14 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
   const int rounds = (S == 1) ? 1 : 2 * S - 1;
   const int zchunks = (S + JAC_ZW - 1) / JAC_ZW;
   const int n_off = S * (S - 1) / 2;
-  auto evd = [&](hipStream_t s, int gbuf, int par, int sweep_slot) {
+  // tiles are swept in full once per outer sweep (its first round), cross-block only otherwise
+  static const bool cross_on = [] { const char* e = std::getenv("XMCA_JACOBI_CROSS"); return !(e && e[0] == '0'); }();
+  auto is_cross = [&](int round_in_sweep) { return cross_on && S > 1 && inner_cap == 1 && round_in_sweep != 0; };
+  auto evd = [&](hipStream_t s, int gbuf, int par, int sweep_slot, int round_in_sweep) {
     hipLaunchKernelGGL((jacobi_tile_evd_kernel<NT, CPLX>), dim3(S), dim3(256), 0, s, ws.G[gbuf][0].get(),
                        CPLX ? ws.G[gbuf][1].get() : nullptr, npad, ws.J[par][0].get(), CPLX ? ws.J[par][1].get() : nullptr,
                        ws.D[par][0].get(), CPLX ? ws.D[par][1].get() : nullptr, tile_tol, ws.scal.get(),
-                       ws.off.get() + sweep_slot, S == 1 ? 60 : inner_cap);
+                       ws.off.get() + sweep_slot, S == 1 ? 60 : inner_cap, is_cross(round_in_sweep) ? 1 : 0);
   };
   auto update = [&](auto mode_tag, hipStream_t s, int par, int grid) {
     constexpr int MODE = decltype(mode_tag)::value;
@@ -578,23 +660,26 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
   int sweeps = 0;
   double off = 0.0;
   int64_t round_no = 0;
-  if (lookahead) evd(st, cur, 0, 0);     // diagonal tiles of the very first round
+  if (lookahead) evd(st, cur, 0, 0, 0);  // diagonal tiles of the very first round
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
     for (int r = 0; r < rounds; ++r, ++round_no) {
-      const int par = (int)(round_no & 1), er = (int)(round_no & 3);
+      const int par = (int)(round_no & 1);
       if (!lookahead) {
-        evd(st, cur, par, sweep);
+        evd(st, cur, par, sweep, r);
         update(std::integral_constant<int, 0>{}, st, par, S + n_off + S * zchunks);
       } else {
-        // head of round r on the main stream; the solve of round r+1 overlaps the bulk of round r
+        // head of round r (diagonal tiles + the S tiles that form the next diagonal), then ONE launch with the
+        // diagonal-tile solves of round r+1 in front of the bulk of round r
         update(std::integral_constant<int, 1>{}, st, par, 2 * S);
-        XMCA_HIP(hipEventRecord(ws.ev_head[er], st));
-        XMCA_HIP(hipStreamWaitEvent(ws.aux, ws.ev_head[er], 0));
         const int next_slot = (r == rounds - 1) ? sweep + 1 : sweep;
-        evd(ws.aux, cur ^ 1, par ^ 1, next_slot);
-        XMCA_HIP(hipEventRecord(ws.ev_evd[er], ws.aux));
-        update(std::integral_constant<int, 2>{}, st, par, n_off + S * zchunks);
-        XMCA_HIP(hipStreamWaitEvent(st, ws.ev_evd[er], 0));
+        hipLaunchKernelGGL((jacobi_fused_round_kernel<NT, CPLX>), dim3(S + n_off + S * zchunks), dim3(256), 0, st,
+                           ws.G[cur][0].get(), CPLX ? ws.G[cur][1].get() : nullptr, ws.G[cur ^ 1][0].get(),
+                           CPLX ? ws.G[cur ^ 1][1].get() : nullptr, ws.Z[cur][0].get(), CPLX ? ws.Z[cur][1].get() : nullptr,
+                           ws.Z[cur ^ 1][0].get(), CPLX ? ws.Z[cur ^ 1][1].get() : nullptr, ws.J[par][0].get(),
+                           CPLX ? ws.J[par][1].get() : nullptr, ws.D[par][0].get(), CPLX ? ws.D[par][1].get() : nullptr,
+                           ws.J[par ^ 1][0].get(), CPLX ? ws.J[par ^ 1][1].get() : nullptr, ws.D[par ^ 1][0].get(),
+                           CPLX ? ws.D[par ^ 1][1].get() : nullptr, tile_tol, ws.scal.get(), ws.off.get() + next_slot,
+                           inner_cap, is_cross((r + 1) % rounds) ? 1 : 0, S, npad);
       }
       cur ^= 1;
     }
@@ -606,7 +691,6 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
     ++sweeps;
     if (S == 1 || !(off >= tol) || !std::isfinite(off)) break;
   }
-  XMCA_HIP(hipStreamSynchronize(ws.aux));
   XMCA_CHECK(std::isfinite(off), XMCA_ERR_NUMERIC, "SVD failed. NaN entries may be the problem.");
 
   // eigenvalues = diagonal; sort descending on the host, drop the padding (= the most negative entries)

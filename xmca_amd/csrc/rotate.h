@@ -317,19 +317,21 @@ template <bool CPLX>
 __global__ __launch_bounds__(256) void varimax_step_kernel(const double* __restrict__ part_r, const double* __restrict__ part_i,
                                                            int nwg, int p, const double* __restrict__ A0r,
                                                            const double* __restrict__ A0i, double* __restrict__ Rr,
-                                                           double* __restrict__ Ri, double* __restrict__ cvec,
+                                                           double* __restrict__ Ri, double* __restrict__ Wr,
+                                                           double* __restrict__ Wi, double* __restrict__ cvec,
                                                            double* __restrict__ state, double tol, int init_only) {
   constexpr int LD = ROT_PMAX + 1;
   __shared__ double Gr[ROT_PMAX][LD], Gi[CPLX ? ROT_PMAX : 1][CPLX ? LD : 1];
   __shared__ double Vr[ROT_PMAX][LD], Vi[CPLX ? ROT_PMAX : 1][CPLX ? LD : 1];
   __shared__ double sig[ROT_PMAX];
+  __shared__ double red2r[256], red2i[CPLX ? 256 : 1];
   __shared__ int flag;
   const int tid = threadIdx.x;
   if (init_only) {
     // R = I, c from A0, state reset
     for (int e = tid; e < p * p; e += 256) {
-      Rr[e] = (e / p == e % p) ? 1.0 : 0.0;
-      if (CPLX) Ri[e] = 0.0;
+      Rr[e] = Wr[e] = (e / p == e % p) ? 1.0 : 0.0;
+      if (CPLX) Ri[e] = Wi[e] = 0.0;
     }
     __syncthreads();
     __threadfence_block();
@@ -339,16 +341,63 @@ __global__ __launch_bounds__(256) void varimax_step_kernel(const double* __restr
   }
   if (state[1] != 0.0 || state[4] != 0.0) return;
 
+  // G = sum of the per-workgroup partials: 256 / p^2 thread slices per entry, combined in a fixed order
+  const int pp = p * p;
+  const int nsl = pp <= 128 ? 256 / pp : 1;
+  if (nsl > 1) {
+    const int sl = tid / pp, e = tid % pp;
+    if (sl < nsl) {
+      double sr = 0.0, si = 0.0;
+      for (int w = sl; w < nwg; w += nsl) {
+        sr += part_r[(int64_t)w * pp + e];
+        if (CPLX) si += part_i[(int64_t)w * pp + e];
+      }
+      red2r[tid] = sr;
+      if (CPLX) red2i[tid] = si;
+    }
+    __syncthreads();
+  }
   for (int e = tid; e < p * p; e += 256) {
     double sr = 0.0, si = 0.0;
-    for (int w = 0; w < nwg; ++w) {
-      sr += part_r[(int64_t)w * p * p + e];
-      if (CPLX) si += part_i[(int64_t)w * p * p + e];
+    if (nsl > 1) {
+      for (int sl = 0; sl < nsl; ++sl) {
+        sr += red2r[sl * pp + e];
+        if (CPLX) si += red2i[sl * pp + e];
+      }
+    } else {
+      for (int w = 0; w < nwg; ++w) {
+        sr += part_r[(int64_t)w * pp + e];
+        if (CPLX) si += part_i[(int64_t)w * pp + e];
+      }
     }
     const int j = e / p, k = e % p;
-    Gr[j][k] = sr;
-    Vr[j][k] = (j == k) ? 1.0 : 0.0;
-    if constexpr (CPLX) { Gi[j][k] = si; Vi[j][k] = 0.0; }
+    // warm start: V <- right singular vectors of the previous iteration (G changes slowly, so G V_prev is already
+    // nearly column-orthogonal and the Jacobi sweeps below converge in one or two passes); G is staged in V's
+    // place for the product and swapped in afterwards.
+    Vr[j][k] = sr;
+    if constexpr (CPLX) Vi[j][k] = si;
+  }
+  __syncthreads();
+  for (int e = tid; e < p * p; e += 256) {
+    const int j = e / p, k = e % p;
+    double ar = 0.0, ai = 0.0;
+    for (int m = 0; m < p; ++m) {
+      const double gr = Vr[j][m], wr = Wr[m * p + k];
+      ar += gr * wr;
+      if constexpr (CPLX) {
+        const double gi = Vi[j][m], wi = Wi[m * p + k];
+        ar -= gi * wi;
+        ai += gr * wi + gi * wr;
+      }
+    }
+    Gr[j][k] = ar;
+    if constexpr (CPLX) Gi[j][k] = ai;
+  }
+  __syncthreads();
+  for (int e = tid; e < p * p; e += 256) {
+    const int j = e / p, k = e % p;
+    Vr[j][k] = Wr[e];
+    if constexpr (CPLX) Vi[j][k] = Wi[e];
   }
   __syncthreads();
 
@@ -383,11 +432,11 @@ __global__ __launch_bounds__(256) void varimax_step_kernel(const double* __restr
         }
         const double g2 = gr * gr + gi * gi;
         if (g2 > 0.0 && g2 > 1e-29 * al * be) {
-          const double ag = sqrt(g2);
-          const double tau = (be - al) / (2.0 * ag);
-          const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-          const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
-          const double sr = s * gr / ag, si = s * gi / ag;
+          // same rotation as in jacobi.h: t = sign(d) 2|g| / (|d| + sqrt(d^2 + 4|g|^2)), one sqrt + one reciprocal
+          const double dd = be - al;
+          const double w = (dd >= 0.0 ? 2.0 : -2.0) / (fabs(dd) + sqrt(dd * dd + 4.0 * g2));
+          const double c = 1.0 / sqrt(1.0 + w * w * g2);
+          const double sr = w * c * gr, si = w * c * gi;
           if (gl == 0) flag = 1;
           for (int i = gl; i < p; i += 16) {
             // new_a = c x - conj(sg) y ; new_b = sg x + c y
@@ -433,25 +482,80 @@ __global__ __launch_bounds__(256) void varimax_step_kernel(const double* __restr
   }
   __syncthreads();
   // R[j][k] = sum_m U[j][m] conj(V[k][m]) = sum_m G[j][m]/s_m * conj(V[k][m])
-  for (int e = tid; e < p * p; e += 256) {
-    const int j = e / p, k = e % p;
-    double rr = 0.0, ri = 0.0;
-    for (int m = 0; m < p; ++m) {
-      const double inv = 1.0 / sig[m];
-      const double ur = Gr[j][m] * inv, vr = Vr[k][m];
-      rr += ur * vr;
-      if constexpr (CPLX) {
-        const double ui = Gi[j][m] * inv, vi = Vi[k][m];
-        rr += ui * vi;              // (ur + i ui)(vr - i vi)
-        ri += ui * vr - ur * vi;
+  double rr_loc[ROT_PMAX * ROT_PMAX / 256], ri_loc[ROT_PMAX * ROT_PMAX / 256];
+  {
+    int slot = 0;
+    for (int e = tid; e < p * p; e += 256, ++slot) {
+      const int j = e / p, k = e % p;
+      double rr = 0.0, ri = 0.0;
+      for (int m = 0; m < p; ++m) {
+        const double inv = 1.0 / sig[m];
+        const double ur = Gr[j][m] * inv, vr = Vr[k][m];
+        rr += ur * vr;
+        if constexpr (CPLX) {
+          const double ui = Gi[j][m] * inv, vi = Vi[k][m];
+          rr += ui * vi;              // (ur + i ui)(vr - i vi)
+          ri += ui * vr - ur * vi;
+        }
       }
+      Rr[e] = rr;
+      Wr[e] = Vr[j][k];
+      if (CPLX) { Ri[e] = ri; Wi[e] = Vi[j][k]; }
+#pragma unroll
+      for (int sl = 0; sl < ROT_PMAX * ROT_PMAX / 256; ++sl)
+        if (sl == slot) { rr_loc[sl] = rr; ri_loc[sl] = ri; }
     }
-    Rr[e] = rr;
-    if (CPLX) Ri[e] = ri;
   }
   __syncthreads();
-  __threadfence_block();
-  rot_colsums<CPLX>(Rr, Ri, A0r, A0i, p, cvec, tid, 256);
+  // next column sums c_k = Re sum_j conj(R[j][k]) (A0 R)[j][k]: stage R in G's place and A0 in V's place
+  {
+    int slot = 0;
+    for (int e = tid; e < p * p; e += 256, ++slot) {
+      const int j = e / p, k = e % p;
+#pragma unroll
+      for (int sl = 0; sl < ROT_PMAX * ROT_PMAX / 256; ++sl)
+        if (sl == slot) { Gr[j][k] = rr_loc[sl]; if constexpr (CPLX) Gi[j][k] = ri_loc[sl]; }
+      Vr[j][k] = A0r[e];
+      if constexpr (CPLX) Vi[j][k] = A0i[e];
+    }
+  }
+  __syncthreads();
+  {
+    int slot = 0;
+    for (int e = tid; e < p * p; e += 256, ++slot) {
+      const int j = e / p, k = e % p;
+      double tr = 0.0, ti = 0.0;
+      for (int l = 0; l < p; ++l) {
+        const double ar = Vr[j][l], r_ = Gr[l][k];
+        tr += ar * r_;
+        if constexpr (CPLX) {
+          const double ai = Vi[j][l], ri_ = Gi[l][k];
+          tr -= ai * ri_;
+          ti += ar * ri_ + ai * r_;
+        }
+      }
+      double prod = Gr[j][k] * tr;
+      if constexpr (CPLX) prod += Gi[j][k] * ti;
+#pragma unroll
+      for (int sl = 0; sl < ROT_PMAX * ROT_PMAX / 256; ++sl)
+        if (sl == slot) rr_loc[sl] = prod;
+    }
+  }
+  __syncthreads();
+  {
+    int slot = 0;
+    for (int e = tid; e < p * p; e += 256, ++slot) {
+#pragma unroll
+      for (int sl = 0; sl < ROT_PMAX * ROT_PMAX / 256; ++sl)
+        if (sl == slot) Vr[e / p][e % p] = rr_loc[sl];
+    }
+  }
+  __syncthreads();
+  for (int k = tid; k < p; k += 256) {
+    double acc = 0.0;
+    for (int j = 0; j < p; ++j) acc += Vr[j][k];
+    cvec[k] = acc;
+  }
   if (tid == 0) {
     double d = 0.0;
     for (int k = 0; k < p; ++k) d += sig[k];

@@ -464,7 +464,7 @@ struct RotateResult {
 
 // Device state of one rotation problem: normalised loadings A (p x N planes), h, R, ...
 struct RotationDevice {
-  CPlanes A, R, A0, acc;
+  CPlanes A, R, A0, acc, W;   // W: right singular vectors of the previous Varimax step (warm start)
   DevBuf<double> h, cvec, state, part_r, part_i, colmax;
   int64_t N = 0, Nleft = 0;
   int p = 0;
@@ -509,6 +509,7 @@ class Rotator {
     d.h.ensure((size_t)N);
     d.R.ensure((size_t)p * p, cplx);
     d.A0.ensure((size_t)p * p, cplx);
+    d.W.ensure((size_t)p * p, cplx);
     d.acc.ensure((size_t)p * p, cplx);
     d.cvec.ensure((size_t)p);
     d.state.ensure(ROT_STATE_N);
@@ -525,7 +526,7 @@ class Rotator {
     tm.begin("varimax");
     accum<CPLX, 1, 0>(d, 1.0, d.A0.r(), d.A0.i(CPLX));
     hipLaunchKernelGGL((varimax_step_kernel<CPLX>), dim3(1), dim3(256), 0, st, d.part_r.get(), CPLX ? d.part_i.get() : nullptr, d.nwg,
-                       p, d.A0.r(), d.A0.i(CPLX), d.R.r(), d.R.i(CPLX), d.cvec.get(), d.state.get(), tol, 1);
+                       p, d.A0.r(), d.A0.i(CPLX), d.R.r(), d.R.i(CPLX), d.W.r(), d.W.i(CPLX), d.cvec.get(), d.state.get(), tol, 1);
     XMCA_HIP(hipGetLastError());
     double state[ROT_STATE_N] = {0};
     int launched = 0;
@@ -534,7 +535,7 @@ class Rotator {
       for (int b = 0; b < batch; ++b) {
         accum<CPLX, 0, 0>(d, 1.0, nullptr, nullptr);
         hipLaunchKernelGGL((varimax_step_kernel<CPLX>), dim3(1), dim3(256), 0, st, d.part_r.get(), CPLX ? d.part_i.get() : nullptr,
-                           d.nwg, p, d.A0.r(), d.A0.i(CPLX), d.R.r(), d.R.i(CPLX), d.cvec.get(), d.state.get(), tol, 0);
+                           d.nwg, p, d.A0.r(), d.A0.i(CPLX), d.R.r(), d.R.i(CPLX), d.W.r(), d.W.i(CPLX), d.cvec.get(), d.state.get(), tol, 0);
       }
       XMCA_HIP(hipGetLastError());
       launched += batch;
