@@ -120,6 +120,11 @@ int xmca_eigh(xmca_handle* h, const double* A, int n, int is_complex, double* la
  * kernel launches alone, flops = useful flops of one product, T (T+1) N. */
 int xmca_bench_gram(xmca_handle* h, int side, int reps, double* avg_ms, double* kernel_ms, double* flops);
 
+/* Time `reps` launches of C = op(A) op(B) on device-resident pseudo-random operands (no host traffic):
+ * avg_ms per product including the split-K reduction when one is used. */
+int xmca_bench_gemm(xmca_handle* h, int M, int N, int K, int dtype, int a_kfast, int b_nfast, int upper_only, int splits,
+                    int reps, double* avg_ms);
+
 #ifdef __cplusplus
 }
 #endif

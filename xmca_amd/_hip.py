@@ -48,6 +48,7 @@ SIGNATURES = {
                            _c_int, _c_int, _c_int]),
     "xmca_eigh": (_c_int, [_vp, _vp, _c_int, _c_int, _vp, _vp, _vp]),
     "xmca_bench_gram": (_c_int, [_vp, _c_int, _c_int, _dp, _dp, _dp]),
+    "xmca_bench_gemm": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _dp]),
 }
 
 _lib = None
@@ -291,6 +292,13 @@ class Handle:
         self._check(self._lib.xmca_eigh(self._h, _ptr(Ad), n, int(cplx), _ptr(lam), _ptr(Zh), _ptr(info)))
         self.last_eigh_info = {"sweeps": int(info[0]), "tile": int(info[1]), "slots": int(info[2])}
         return lam, Zh.conj().T
+
+    def bench_gemm(self, M, N, K, dtype, a_kfast=True, b_nfast=True, upper_only=False, splits=0, reps=5):
+        """ms per product C = op(A) op(B) on device-resident random operands."""
+        ms = _c_dbl(0)
+        self._check(self._lib.xmca_bench_gemm(self._h, M, N, K, _np_dtype_code(dtype), int(a_kfast), int(b_nfast), int(upper_only),
+                                              int(splits), int(reps), ctypes.byref(ms)))
+        return ms.value
 
     def bench_gram(self, side, reps):
         a, k, f = _c_dbl(0), _c_dbl(0), _c_dbl(0)

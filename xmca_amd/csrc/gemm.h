@@ -1,34 +1,46 @@
 // MFMA GEMM for gfx950: C[MxN] = alpha * rs[m] * cs[n] * op(A) * op(B) + beta * C
 //
 // * f64 operands -> v_mfma_f64_16x16x4_f64, f32 operands -> v_mfma_f32_16x16x4_f32
-//   (exact f32, optionally flushed into f64 side accumulators every FLUSH_TILES k-tiles
-//   so that long contractions keep f64-class accumulation error: "WIDE").
-// * 128x128 block tile, BK = 16, 4 waves (2x2), each wave 64x64 = 4x4 MFMA tiles.
-// * operands are staged global -> registers -> LDS (k-major, padded) with a register
-//   prefetch of the next k-tile while the current one feeds the matrix pipe.
-// * All four operand orientations of row-major storage are supported so that no
-//   transposed copy of a space x time field is ever materialised:
+//   (exact f32, flushed into f64 side accumulators every FLUSH_TILES k-tiles so that long contractions keep
+//   f64-class accumulation error: "WIDE").
+// * 128x128 block tile, BK = 32, 512 threads = 8 waves (2 x 4), each wave 64x32 = 4x2 MFMA tiles
+//   (~130 VGPRs -> two workgroups per CU).
+// * operands are staged global -> registers -> LDS (k-major, padded); the loads of the next k-tile are in flight
+//   while the current one feeds the matrix pipe.  Global reads are 16-byte vectors along the contiguous axis:
+//   a k-contiguous operand is read in 256-byte (f64) / 128-byte (f32) row segments.
+// * All four operand orientations of row-major storage are supported, so no transposed copy of a space x time
+//   field is ever materialised:
 //       A_KFAST: A(m,k) = A[m*lda + k]   else  A(m,k) = A[k*lda + m]
 //       B_NFAST: B(k,n) = B[k*ldb + n]   else  B(k,n) = B[n*ldb + k]
-// * upper_only: compute only block tiles with bn >= bm (Gram / Hermitian products);
+// * upper_only: only block tiles with bn >= bm are launched (Gram / Hermitian products);
 //   mirror = +1/-1 writes the (anti)symmetric counterpart of off-diagonal tiles.
-// * split-K through blockIdx.z into an f64 workspace + reduce kernel (deterministic).
+// * the (split, tile) list is dealt to the 8 XCDs in contiguous ranges (workgroup b runs on XCD b % 8), so the
+//   workgroups sharing one L2 work on neighbouring tiles of the same k-slice.
+// * split-K through an f64 workspace + reduce kernel (deterministic).
 //
 // Reference call sites this replaces: numpy `@` / gesdd inner products of
 // xmca/array.py:552-566 and :580-584 (see DESIGN.md for the formulation).
 #pragma once
+#include <algorithm>
+#include <memory>
+#include <type_traits>
+#include <vector>
+
 #include "common.h"
 
 namespace xmca {
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
 typedef float f4_t __attribute__((ext_vector_type(4)));
+typedef double d2_t __attribute__((ext_vector_type(2)));
 
 template <typename T>
 struct Mfma;
 template <>
 struct Mfma<double> {
   using acc_t = d4_t;
+  using vec_t = d2_t;
+  static constexpr int VW = 2;
   static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
   }
@@ -38,6 +50,8 @@ struct Mfma<double> {
 template <>
 struct Mfma<float> {
   using acc_t = f4_t;
+  using vec_t = f4_t;
+  static constexpr int VW = 4;
   static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
   }
@@ -45,8 +59,13 @@ struct Mfma<float> {
   static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) * 4 + r; }
 };
 
-constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 16, GEMM_LDS_LD = 130;
-constexpr int GEMM_FLUSH_TILES = 32;  // WIDE: f32 partial sums cover at most 32*16 = 512 products
+constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 32, GEMM_THREADS = 512;
+// LDS row pitch (elements).  A k-contiguous operand is stored TRANSPOSED into the k-major LDS tile with scalar
+// writes: pitch 129 puts the 16 (f64) / 32 (f32) lanes of a write group on distinct banks.  An m/n-contiguous operand
+// is stored with 16-byte vector writes: pitch 132 keeps every row 16-byte aligned for f32 and f64.
+template <bool FAST_K>
+struct GemmPitch { static constexpr int value = FAST_K ? 129 : 132; };
+constexpr int GEMM_FLUSH_TILES = 16;  // WIDE: f32 partial sums cover at most 16 * 32 = 512 products
 
 template <typename TI, typename TO>
 struct GemmParams {
@@ -60,124 +79,169 @@ struct GemmParams {
   const double* col_scale;  // nullable, length N
   int upper_only;
   int mirror;
-  int k_chunk;              // contraction length handled by one blockIdx.z slice
+  int k_chunk;              // contraction length handled by one split
   int64_t split_stride;     // elements between consecutive split-K slices of C
+  int n_tiles;              // block tiles per split (upper triangle only when upper_only)
+  int n_wg;                 // n_tiles * splits
+  const int* tile_map;      // n_tiles packed (bm << 16 | bn) in super-block order
+  int vec_a, vec_b;         // 16-byte vector loads allowed (base and leading dimension aligned)
 };
 
-template <typename TI, typename TO, bool A_KFAST, bool B_NFAST, bool WIDE>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmParams<TI, TO> p) {
+// One (128 x 32) operand tile: 8 elements per thread as NV vectors of VW.
+//   FAST_K: the global array is contiguous along k (row index = m/n), else contiguous along m/n (row index = k).
+template <typename TI, bool FAST_K>
+struct GemmTileIO {
+  static constexpr int VW = Mfma<TI>::VW, NV = 8 / VW;
+  static constexpr int PITCH = GemmPitch<FAST_K>::value;
+  using vec_t = typename Mfma<TI>::vec_t;
+  // position of vector i of this thread inside the tile: r along the 128-wide axis, k along the contraction axis
+  static __device__ __forceinline__ void pos(int i, int& r, int& k) {
+    const int v = i * GEMM_THREADS + (int)threadIdx.x;
+    if constexpr (FAST_K) { r = v / (GEMM_BK / VW); k = (v % (GEMM_BK / VW)) * VW; }
+    else                  { k = v / (GEMM_BM / VW); r = (v % (GEMM_BM / VW)) * VW; }
+  }
+  // interior tile: unpredicated 16-byte loads from a per-thread base pointer (tile origin already applied)
+  static __device__ __forceinline__ void load_fast(const TI* __restrict__ base, int64_t ld, TI (&reg)[8]) {
+    int r0, k0;
+    pos(0, r0, k0);
+    const TI* p0 = FAST_K ? base + (int64_t)r0 * ld + k0 : base + (int64_t)k0 * ld + r0;
+    // consecutive vectors of a thread are a fixed number of rows apart
+    constexpr int STEP = FAST_K ? GEMM_THREADS / (GEMM_BK / VW) : GEMM_THREADS / (GEMM_BM / VW);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const vec_t x = *reinterpret_cast<const vec_t*>(p0 + (int64_t)i * STEP * ld);
+#pragma unroll
+      for (int j = 0; j < VW; ++j) reg[i * VW + j] = x[j];
+    }
+  }
+  // edge tile / unaligned operand: element-wise, zero filled
+  static __device__ __forceinline__ void load_slow(const TI* __restrict__ P, int64_t ld, int row0, int rows, int k0, int kend,
+                                                   TI (&reg)[8]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int r, k;
+      pos(i, r, k);
+#pragma unroll
+      for (int j = 0; j < VW; ++j) {
+        const int er = row0 + (FAST_K ? r : r + j), ek = k0 + (FAST_K ? k + j : k);
+        TI x = TI(0);
+        if (er < rows && ek < kend) x = FAST_K ? P[(int64_t)er * ld + ek] : P[(int64_t)ek * ld + er];
+        reg[i * VW + j] = x;
+      }
+    }
+  }
+  static __device__ __forceinline__ void store(TI (*S)[PITCH], const TI (&reg)[8]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int r, k;
+      pos(i, r, k);
+      if constexpr (FAST_K) {
+#pragma unroll
+        for (int j = 0; j < VW; ++j) S[k + j][r] = reg[i * VW + j];
+      } else {
+        vec_t x;
+#pragma unroll
+        for (int j = 0; j < VW; ++j) x[j] = reg[i * VW + j];
+        *reinterpret_cast<vec_t*>(&S[k][r]) = x;
+      }
+    }
+  }
+};
+
+// MINW = minimum waves per SIMD the register allocation must allow: 4 -> two 512-thread workgroups per CU
+// (<= 128 VGPRs), 2 -> one workgroup per CU.
+template <typename TI, typename TO, bool A_KFAST, bool B_NFAST, bool WIDE, int MINW>
+__global__ __launch_bounds__(GEMM_THREADS, MINW) void gemm_kernel(GemmParams<TI, TO> p) {
   using M_ = Mfma<TI>;
   using acc_t = typename M_::acc_t;
-  __shared__ TI As[2][GEMM_BK][GEMM_LDS_LD];
-  __shared__ TI Bs[2][GEMM_BK][GEMM_LDS_LD];
+  using IOA = GemmTileIO<TI, A_KFAST>;
+  using IOB = GemmTileIO<TI, !B_NFAST>;
+  __shared__ __attribute__((aligned(16))) TI As[GEMM_BK][IOA::PITCH];
+  __shared__ __attribute__((aligned(16))) TI Bs[GEMM_BK][IOB::PITCH];
 
-  const int tiles_n = (p.N + GEMM_BN - 1) / GEMM_BN;
-  const int bm = blockIdx.x / tiles_n, bn = blockIdx.x % tiles_n;
-  if (p.upper_only && bn < bm) return;
+  // XCD-aware, bijective remap of the launch index (cdna_hip_programming.md T1)
+  int L;
+  {
+    const int b = blockIdx.x, q = p.n_wg / 8, r = p.n_wg % 8, xcd = b % 8, idx = b / 8;
+    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int split = L / p.n_tiles;
+  const int packed = p.tile_map[L % p.n_tiles];
+  const int bm = packed >> 16, bn = packed & 0xffff;
   const int bm0 = bm * GEMM_BM, bn0 = bn * GEMM_BN;
-  const int kbeg = blockIdx.z * p.k_chunk;
+  const int kbeg = split * p.k_chunk;
   const int kend = min(p.K, kbeg + p.k_chunk);
-  TO* __restrict__ C = p.C + (int64_t)blockIdx.z * p.split_stride;
+  TO* __restrict__ C = p.C + (int64_t)split * p.split_stride;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int wm = (wave >> 2) * 64, wn = (wave & 3) * 32;
   const int l15 = lane & 15, l4 = lane >> 4;
 
-  acc_t acc[4][4];
-  d4_t wide[WIDE ? 4 : 1][WIDE ? 4 : 1];
+  acc_t acc[4][2];
+  d4_t wide[WIDE ? 4 : 1][WIDE ? 2 : 1];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 2; ++j) {
       acc[i][j] = acc_t{0, 0, 0, 0};
       if constexpr (WIDE) wide[i][j] = d4_t{0, 0, 0, 0};
     }
 
+  // workgroup-uniform: whole tile inside the matrices and both operands 16-byte aligned -> unpredicated vector loads
+  const bool interior = (bm0 + GEMM_BM <= p.M) && (bn0 + GEMM_BN <= p.N) && p.vec_a && p.vec_b;
+  const TI* __restrict__ baseA = A_KFAST ? p.A + (int64_t)bm0 * p.lda : p.A + bm0;   // + k offset per tile
+  const TI* __restrict__ baseB = B_NFAST ? p.B + bn0 : p.B + (int64_t)bn0 * p.ldb;
+  const int64_t kstepA = A_KFAST ? 1 : p.lda, kstepB = B_NFAST ? p.ldb : 1;
   TI ra[8], rb[8];
-  auto load_tile = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      int m, kk;
-      if constexpr (A_KFAST) { m = (tid >> 4) + 16 * i; kk = tid & 15; }
-      else                   { kk = 2 * i + (tid >> 7); m = tid & 127; }
-      const int gm = bm0 + m, gk = k0 + kk;
-      TI v = TI(0);
-      if (gm < p.M && gk < kend)
-        v = A_KFAST ? p.A[(int64_t)gm * p.lda + gk] : p.A[(int64_t)gk * p.lda + gm];
-      ra[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      int n, kk;
-      if constexpr (B_NFAST) { kk = 2 * i + (tid >> 7); n = tid & 127; }
-      else                   { n = (tid >> 4) + 16 * i; kk = tid & 15; }
-      const int gn = bn0 + n, gk = k0 + kk;
-      TI v = TI(0);
-      if (gn < p.N && gk < kend)
-        v = B_NFAST ? p.B[(int64_t)gk * p.ldb + gn] : p.B[(int64_t)gn * p.ldb + gk];
-      rb[i] = v;
+  auto load = [&](int k0) {
+    if (interior && k0 + GEMM_BK <= kend) {
+      IOA::load_fast(baseA + (int64_t)k0 * kstepA, p.lda, ra);
+      IOB::load_fast(baseB + (int64_t)k0 * kstepB, p.ldb, rb);
+    } else {
+      IOA::load_slow(p.A, p.lda, bm0, p.M, k0, kend, ra);
+      IOB::load_slow(p.B, p.ldb, bn0, p.N, k0, kend, rb);
     }
   };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      int m, kk;
-      if constexpr (A_KFAST) { m = (tid >> 4) + 16 * i; kk = tid & 15; }
-      else                   { kk = 2 * i + (tid >> 7); m = tid & 127; }
-      As[buf][kk][m] = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      int n, kk;
-      if constexpr (B_NFAST) { kk = 2 * i + (tid >> 7); n = tid & 127; }
-      else                   { n = (tid >> 4) + 16 * i; kk = tid & 15; }
-      Bs[buf][kk][n] = rb[i];
-    }
-  };
-
   const int nkt = (kend - kbeg + GEMM_BK - 1) / GEMM_BK;
-  if (nkt > 0) {
-    load_tile(kbeg);
-    store_tile(0);
-  }
-  __syncthreads();
+  if (nkt > 0) load(kbeg);
   for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nkt) load_tile(kbeg + (kt + 1) * GEMM_BK);
+    IOA::store(As, ra);
+    IOB::store(Bs, rb);
+    __syncthreads();
+    if (kt + 1 < nkt) load(kbeg + (kt + 1) * GEMM_BK);
 #pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4) {
+    for (int k4 = 0; k4 < GEMM_BK / 4; ++k4) {
       const int kr = k4 * 4 + l4;
-      TI a[4], b[4];
+      TI a[4], b[2];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = As[cur][kr][wm + i * 16 + l15];
+      for (int i = 0; i < 4; ++i) a[i] = As[kr][wm + i * 16 + l15];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = Bs[cur][kr][wn + j * 16 + l15];
+      for (int j = 0; j < 2; ++j) b[j] = Bs[kr][wn + j * 16 + l15];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = M_::mma(a[i], b[j], acc[i][j]);
+        for (int j = 0; j < 2; ++j) acc[i][j] = M_::mma(a[i], b[j], acc[i][j]);
     }
     if constexpr (WIDE) {
       if ((kt % GEMM_FLUSH_TILES) == GEMM_FLUSH_TILES - 1) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
+          for (int j = 0; j < 2; ++j) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) wide[i][j][r] += (double)acc[i][j][r];
             acc[i][j] = acc_t{0, 0, 0, 0};
           }
       }
     }
-    if (kt + 1 < nkt) store_tile(cur ^ 1);
-    __syncthreads();
+    __syncthreads();   // every wave is done with this k-tile before it is overwritten
   }
 
   const bool offdiag = (bm != bn);
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = bm0 + wm + i * 16 + M_::row(lane, r);
@@ -229,18 +293,48 @@ struct GemmOpts {
   int force_splits = 0;  // 0 = heuristic
 };
 
-// scratch for split-K partial sums, owned by the caller (one per stream)
+// scratch for split-K partial sums and the tile-order tables, owned by the caller (one per stream)
 struct GemmWorkspace {
   DevBuf<double> partial;
+  struct Map { int tm, tn, upper; DevBuf<int> dev; int n; };
+  std::vector<std::unique_ptr<Map>> maps;
+
+  // Tiles are enumerated in 8 x 8 super-blocks: the ~64 workgroups that share one XCD's L2 at a time then touch only
+  // 8 + 8 operand panels, so each panel slice is fetched from HBM / Infinity Cache once per XCD and reused from L2.
+  const Map& tile_map(hipStream_t st, int tm, int tn, bool upper) {
+    for (auto& m : maps)
+      if (m->tm == tm && m->tn == tn && m->upper == (int)upper) return *m;
+    constexpr int G = 8;
+    std::vector<int> order;
+    for (int si = 0; si < tm; si += G)
+      for (int sj = upper ? si : 0; sj < tn; sj += G)
+        for (int i = si; i < std::min(si + G, tm); ++i)
+          for (int j = sj; j < std::min(sj + G, tn); ++j)
+            if (!upper || j >= i) order.push_back((i << 16) | j);
+    auto m = std::make_unique<Map>();
+    m->tm = tm; m->tn = tn; m->upper = upper; m->n = (int)order.size();
+    XMCA_HIP(hipMemcpyAsync(m->dev.ensure(order.size()), order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice, st));
+    XMCA_HIP(hipStreamSynchronize(st));
+    maps.push_back(std::move(m));
+    return *maps.back();
+  }
 };
 
 template <typename TI, typename TO, bool WIDE>
-static void launch_gemm_variant(hipStream_t st, const GemmParams<TI, TO>& p, dim3 grid, bool a_kfast, bool b_nfast) {
-  dim3 block(256);
-  if (a_kfast && b_nfast) hipLaunchKernelGGL((gemm_kernel<TI, TO, true, true, WIDE>), grid, block, 0, st, p);
-  else if (a_kfast && !b_nfast) hipLaunchKernelGGL((gemm_kernel<TI, TO, true, false, WIDE>), grid, block, 0, st, p);
-  else if (!a_kfast && b_nfast) hipLaunchKernelGGL((gemm_kernel<TI, TO, false, true, WIDE>), grid, block, 0, st, p);
-  else hipLaunchKernelGGL((gemm_kernel<TI, TO, false, false, WIDE>), grid, block, 0, st, p);
+static void launch_gemm_variant(hipStream_t st, const GemmParams<TI, TO>& p, bool a_kfast, bool b_nfast) {
+  dim3 grid(p.n_wg), block(GEMM_THREADS);
+  static const int minw = [] { const char* e = std::getenv("XMCA_GEMM_MINW"); return (e && e[0] == '2') ? 2 : 4; }();
+  if (minw == 4) {
+    if (a_kfast && b_nfast) hipLaunchKernelGGL((gemm_kernel<TI, TO, true, true, WIDE, 4>), grid, block, 0, st, p);
+    else if (a_kfast && !b_nfast) hipLaunchKernelGGL((gemm_kernel<TI, TO, true, false, WIDE, 4>), grid, block, 0, st, p);
+    else if (!a_kfast && b_nfast) hipLaunchKernelGGL((gemm_kernel<TI, TO, false, true, WIDE, 4>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((gemm_kernel<TI, TO, false, false, WIDE, 4>), grid, block, 0, st, p);
+  } else {
+    if (a_kfast && b_nfast) hipLaunchKernelGGL((gemm_kernel<TI, TO, true, true, WIDE, 2>), grid, block, 0, st, p);
+    else if (a_kfast && !b_nfast) hipLaunchKernelGGL((gemm_kernel<TI, TO, true, false, WIDE, 2>), grid, block, 0, st, p);
+    else if (!a_kfast && b_nfast) hipLaunchKernelGGL((gemm_kernel<TI, TO, false, true, WIDE, 2>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((gemm_kernel<TI, TO, false, false, WIDE, 2>), grid, block, 0, st, p);
+  }
   XMCA_HIP(hipGetLastError());
 }
 
@@ -255,19 +349,33 @@ void gemm(hipStream_t st, GemmWorkspace& ws, const TI* A, int64_t lda, const TI*
   const int nkt = ceil_div(K, GEMM_BK);
   int splits = o.force_splits;
   if (splits <= 0) {
+    // Cost model in units of one k-tile of one workgroup round (two workgroups share a CU -> 512 slots):
+    //   rounds(s) * (k-tiles per slice + ~6 tiles of prologue/epilogue) + s * (partial-sum traffic of one slice).
+    // Picks the slice count that fills whole rounds of the chip (a 276-tile Gram at 6 slices wastes 19 % in its
+    // last round, at 5 slices 10 %) without drowning in partial sums; slices stay <= 16k products deep so the
+    // panels of concurrently running tiles stay cache resident.
     splits = 1;
-    if (tiles < 512 && nkt >= 64) {
-      splits = (int)((768 + tiles - 1) / tiles);
-      const int max_by_k = nkt / 32 > 0 ? nkt / 32 : 1;   // at least 32 k-tiles (512 products) per slice
-      if (splits > max_by_k) splits = max_by_k;
-      if (splits > 64) splits = 64;
+    if (nkt >= 32) {
+      const int max_s = std::min(std::max(nkt / 8, 1), 128);
+      const int min_s = std::min(ceil_div(nkt, 512), max_s);
+      double best = 1e300;
+      for (int s_ = std::max(min_s, 1); s_ <= max_s; ++s_) {
+        const double rounds = std::ceil((double)tiles * s_ / 512.0);
+        const double cost = rounds * ((double)nkt / s_ + 6.0) * 2.0 + (s_ > 1 ? s_ * (double)tiles / 35.0 : 0.0);
+        if (cost < best) { best = cost; splits = s_; }
+      }
     }
   }
+  const GemmWorkspace::Map& map = ws.tile_map(st, tm, tn, o.upper_only);
+  XMCA_CHECK(map.n == tiles && tm < 65536 && tn < 65536, XMCA_ERR_INVALID, "gemm: tile map mismatch");
   constexpr bool WIDE = std::is_same<TI, float>::value;
+  constexpr int VW = Mfma<TI>::VW;
+  const int vec_a = (lda % VW == 0) && (reinterpret_cast<uintptr_t>(A) % 16 == 0);
+  const int vec_b = (ldb % VW == 0) && (reinterpret_cast<uintptr_t>(B) % 16 == 0);
   if (splits <= 1 || K == 0) {
     GemmParams<TI, TO> p{A, B, C, M, N, K, lda, ldb, ldc, o.alpha, o.beta, o.row_scale, o.col_scale,
-                         o.upper_only ? 1 : 0, o.mirror, K > 0 ? K : 1, 0};
-    launch_gemm_variant<TI, TO, WIDE>(st, p, dim3(tm * tn, 1, 1), o.a_kfast, o.b_nfast);
+                         o.upper_only ? 1 : 0, o.mirror, K > 0 ? K : 1, 0, (int)tiles, (int)tiles, map.dev.get(), vec_a, vec_b};
+    launch_gemm_variant<TI, TO, WIDE>(st, p, o.a_kfast, o.b_nfast);
     return;
   }
   int k_chunk = ceil_div(nkt, splits) * GEMM_BK;
@@ -275,10 +383,9 @@ void gemm(hipStream_t st, GemmWorkspace& ws, const TI* A, int64_t lda, const TI*
   const int64_t stride = (int64_t)M * N;
   double* W = ws.partial.ensure((size_t)stride * splits);
   GemmParams<TI, double> p{A, B, W, M, N, K, lda, ldb, (int64_t)N, 1.0, 0.0, nullptr, nullptr,
-                           o.upper_only ? 1 : 0, 0, k_chunk, stride};
-  launch_gemm_variant<TI, double, WIDE>(st, p, dim3(tm * tn, 1, splits), o.a_kfast, o.b_nfast);
-  const int64_t total = stride;
-  hipLaunchKernelGGL((splitk_reduce_kernel<TO>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, splits, stride, C,
+                           o.upper_only ? 1 : 0, 0, k_chunk, stride, (int)tiles, (int)(tiles * splits), map.dev.get(), vec_a, vec_b};
+  launch_gemm_variant<TI, double, WIDE>(st, p, o.a_kfast, o.b_nfast);
+  hipLaunchKernelGGL((splitk_reduce_kernel<TO>), dim3((unsigned)((stride + 255) / 256)), dim3(256), 0, st, W, splits, stride, C,
                      M, N, ldc, o.alpha, o.beta, o.row_scale, o.col_scale, o.upper_only ? 1 : 0, o.mirror);
   XMCA_HIP(hipGetLastError());
 }

@@ -255,6 +255,38 @@ void rule_n_impl(xmca_handle* h, int64_t T, int64_t Nx, int64_t Ny, int n_fields
 
 }  // namespace
 
+template <typename TI>
+static void bench_gemm_impl(xmca_handle* h, int M, int N, int K, int a_kfast, int b_nfast, int upper_only, int splits, int reps,
+                            double* avg_ms) {
+  const int64_t lda = a_kfast ? K : M, ldb = b_nfast ? N : K;
+  const size_t na = (size_t)(a_kfast ? M : K) * lda, nb = (size_t)(b_nfast ? K : N) * ldb;
+  DevBuf<TI> A, B;
+  DevBuf<double> C;
+  hipLaunchKernelGGL((philox_normal_kernel<TI>), ew_grid((int64_t)(na + 1) / 2), dim3(EW_BLOCK), 0, h->st, A.ensure(na), (int64_t)na,
+                     (uint64_t)1, 0u, 0u);
+  hipLaunchKernelGGL((philox_normal_kernel<TI>), ew_grid((int64_t)(nb + 1) / 2), dim3(EW_BLOCK), 0, h->st, B.ensure(nb), (int64_t)nb,
+                     (uint64_t)2, 0u, 1u);
+  C.ensure((size_t)M * N);
+  GemmOpts o;
+  o.a_kfast = a_kfast != 0; o.b_nfast = b_nfast != 0; o.upper_only = upper_only != 0; o.mirror = upper_only ? 1 : 0;
+  o.force_splits = splits;
+  hipEvent_t e0, e1;
+  XMCA_HIP(hipEventCreate(&e0));
+  XMCA_HIP(hipEventCreate(&e1));
+  gemm<TI, double>(h->st, h->gws, A.get(), lda, B.get(), ldb, C.get(), N, M, N, K, o);
+  XMCA_HIP(hipStreamSynchronize(h->st));
+  XMCA_HIP(hipEventRecord(e0, h->st));
+  for (int i = 0; i < reps; ++i) gemm<TI, double>(h->st, h->gws, A.get(), lda, B.get(), ldb, C.get(), N, M, N, K, o);
+  XMCA_HIP(hipEventRecord(e1, h->st));
+  XMCA_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  XMCA_HIP(hipEventElapsedTime(&ms, e0, e1));
+  *avg_ms = ms / reps;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+}
+
+
 extern "C" {
 
 int xmca_set_field(xmca_handle* h, int side, const void* re, const void* im, int64_t T, int64_t N, int dtype, int location) {
@@ -514,6 +546,16 @@ int xmca_bench_gram(xmca_handle* h, int side, int reps, double* avg_ms, double* 
   if (flops) *flops = (double)T * (double)(T + 1) * (double)N;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+  API_END(h)
+}
+
+
+int xmca_bench_gemm(xmca_handle* h, int M, int N, int K, int dtype, int a_kfast, int b_nfast, int upper_only, int splits,
+                    int reps, double* avg_ms) {
+  API_BEGIN(h)
+  XMCA_CHECK(M > 0 && N > 0 && K > 0 && reps > 0 && avg_ms, XMCA_ERR_INVALID, "bench_gemm: bad arguments");
+  if (dtype == XMCA_F32) bench_gemm_impl<float>(h, M, N, K, a_kfast, b_nfast, upper_only, splits, reps, avg_ms);
+  else bench_gemm_impl<double>(h, M, N, K, a_kfast, b_nfast, upper_only, splits, reps, avg_ms);
   API_END(h)
 }
 
