@@ -104,11 +104,18 @@ def main():
     value = world * args.steps / elapsed
 
     # ---- roofline of the covariance (Gram) GEMM, measured live with hipEvents on the library's stream ----
+    # achieved = algorithmic flops T(T+1)N of one Gram product / average duration of the MFMA kernel launch
+    # (hipEvents recorded around that launch on the library's stream); the product including its split-K reduction
+    # is reported next to it.  traffic: HBM-side bytes per launch of the same kernel on the same workload from
+    # rocprofv3 PMC passes (profiles/r01_pmc_gram_c2.json: (2*FETCH_SIZE + WRITE_SIZE) * 1024, gfx950 correction).
     g = h.bench_gram(0, 5)
-    gram_tf = g["flops"] / (g["avg_ms"] * 1e-3) / 1e12
-    roofline = {"kernel": "gemm_kernel<f64> (Gram X X^T, v_mfma_f64_16x16x4_f64, upper triangle)", "bound": "mfma",
+    gram_tf = g["flops"] / (g["kernel_ms"] * 1e-3) / 1e12
+    default_workload = (T, N) == (2920, 10_000)
+    roofline = {"kernel": "gemm_kernel<f64> (Gram X X^T, v_mfma_f64_16x16x4_f64, upper block triangle)", "bound": "mfma",
                 "achieved": gram_tf, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": gram_tf / F64_MFMA_PEAK_TF,
-                "traffic": None, "flops_per_launch": g["flops"], "avg_ms": g["avg_ms"]}
+                "traffic": 2.238e9 if default_workload else None, "flops_per_launch": g["flops"],
+                "avg_launch_ms": g["kernel_ms"], "product_ms_incl_splitk_reduce": g["avg_ms"],
+                "algorithmic_bytes": 8.0 * (T * N + T * T)}
 
     extra = {}
     # cheap self-check of the timed result (full parity against the oracle is in cpu_baseline/parity and tests/)

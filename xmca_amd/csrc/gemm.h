@@ -291,6 +291,7 @@ struct GemmOpts {
   bool upper_only = false;
   int mirror = 0;
   int force_splits = 0;  // 0 = heuristic
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr;   // optional: recorded around the MFMA kernel launch alone
 };
 
 // scratch for split-K partial sums and the tile-order tables, owned by the caller (one per stream)
@@ -375,7 +376,9 @@ void gemm(hipStream_t st, GemmWorkspace& ws, const TI* A, int64_t lda, const TI*
   if (splits <= 1 || K == 0) {
     GemmParams<TI, TO> p{A, B, C, M, N, K, lda, ldb, ldc, o.alpha, o.beta, o.row_scale, o.col_scale,
                          o.upper_only ? 1 : 0, o.mirror, K > 0 ? K : 1, 0, (int)tiles, (int)tiles, map.dev.get(), vec_a, vec_b};
+    if (o.ev_begin) XMCA_HIP(hipEventRecord(o.ev_begin, st));
     launch_gemm_variant<TI, TO, WIDE>(st, p, o.a_kfast, o.b_nfast);
+    if (o.ev_end) XMCA_HIP(hipEventRecord(o.ev_end, st));
     return;
   }
   int k_chunk = ceil_div(nkt, splits) * GEMM_BK;
@@ -384,7 +387,9 @@ void gemm(hipStream_t st, GemmWorkspace& ws, const TI* A, int64_t lda, const TI*
   double* W = ws.partial.ensure((size_t)stride * splits);
   GemmParams<TI, double> p{A, B, W, M, N, K, lda, ldb, (int64_t)N, 1.0, 0.0, nullptr, nullptr,
                            o.upper_only ? 1 : 0, 0, k_chunk, stride, (int)tiles, (int)(tiles * splits), map.dev.get(), vec_a, vec_b};
+  if (o.ev_begin) XMCA_HIP(hipEventRecord(o.ev_begin, st));
   launch_gemm_variant<TI, double, WIDE>(st, p, o.a_kfast, o.b_nfast);
+  if (o.ev_end) XMCA_HIP(hipEventRecord(o.ev_end, st));
   hipLaunchKernelGGL((splitk_reduce_kernel<TO>), dim3((unsigned)((stride + 255) / 256)), dim3(256), 0, st, W, splits, stride, C,
                      M, N, ldc, o.alpha, o.beta, o.row_scale, o.col_scale, o.upper_only ? 1 : 0, o.mirror);
   XMCA_HIP(hipGetLastError());

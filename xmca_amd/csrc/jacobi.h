@@ -71,8 +71,11 @@ __global__ void jacobi_init_kernel(const double* __restrict__ Ar, const double* 
     gr = -scal[0];
   }
   Gr[idx] = gr;
-  Zr[idx] = (r == c) ? 1.0 : 0.0;
-  if (Gi) { Gi[idx] = gi; Zi[idx] = 0.0; }
+  if (Gi) Gi[idx] = gi;
+  if (Zr) {      // eigenvectors wanted
+    Zr[idx] = (r == c) ? 1.0 : 0.0;
+    if (Zi) Zi[idx] = 0.0;
+  }
 }
 
 // LDS images of the two kernel bodies (a fused launch runs both kinds of workgroups, so they share one union)
@@ -608,12 +611,18 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
   const int S = std::max(ceil_div(n, NT), 1);
   const int npad = S * NT;
   const size_t nn = (size_t)npad * npad;
+  const bool want_z = Zr != nullptr;      // eigenvalues only: the eigenvector tiles (half of the work) are skipped
   for (int b = 0; b < 2; ++b) {
     ws.G[b][0].ensure(nn);
-    ws.Z[b][0].ensure(nn);
+    if (want_z) ws.Z[b][0].ensure(nn);
     ws.J[b][0].ensure((size_t)S * NT * NT);
     ws.D[b][0].ensure((size_t)S * NT * NT);
-    if (CPLX) { ws.G[b][1].ensure(nn); ws.Z[b][1].ensure(nn); ws.J[b][1].ensure((size_t)S * NT * NT); ws.D[b][1].ensure((size_t)S * NT * NT); }
+    if (CPLX) {
+      ws.G[b][1].ensure(nn);
+      if (want_z) ws.Z[b][1].ensure(nn);
+      ws.J[b][1].ensure((size_t)S * NT * NT);
+      ws.D[b][1].ensure((size_t)S * NT * NT);
+    }
   }
   ws.diag.ensure((size_t)npad);
   ws.scal.ensure(2);
@@ -624,8 +633,8 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
   XMCA_HIP(hipMemsetAsync(ws.off.get(), 0, sizeof(unsigned long long) * JAC_OFF_RING, st));
   hipLaunchKernelGGL(jacobi_init_scale_kernel, dim3(1), dim3(256), 0, st, Ar, n, lda, tol, ws.scal.get());
   hipLaunchKernelGGL(jacobi_init_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, Ar, CPLX ? Ai : nullptr, n, lda,
-                     ws.G[0][0].get(), CPLX ? ws.G[0][1].get() : nullptr, ws.Z[0][0].get(), CPLX ? ws.Z[0][1].get() : nullptr,
-                     npad, ws.scal.get());
+                     ws.G[0][0].get(), CPLX ? ws.G[0][1].get() : nullptr, want_z ? ws.Z[0][0].get() : nullptr,
+                     (CPLX && want_z) ? ws.Z[0][1].get() : nullptr, npad, ws.scal.get());
   XMCA_HIP(hipGetLastError());
 
   const double tile_tol = 2e-15;
@@ -637,7 +646,7 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
 
   int cur = 0;
   const int rounds = (S == 1) ? 1 : 2 * S - 1;
-  const int zchunks = (S + JAC_ZW - 1) / JAC_ZW;
+  const int zchunks = want_z ? (S + JAC_ZW - 1) / JAC_ZW : 0;   // 0: the launches simply do not contain Z tiles
   const int n_off = S * (S - 1) / 2;
   // tiles are swept in full once per outer sweep (its first round), cross-block only otherwise
   static const bool cross_on = [] { const char* e = std::getenv("XMCA_JACOBI_CROSS"); return !(e && e[0] == '0'); }();
@@ -689,6 +698,8 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
     XMCA_HIP(hipStreamSynchronize(st));
     std::memcpy(&off, &bits, sizeof(double));
     ++sweeps;
+    static const bool trace = std::getenv("XMCA_JACOBI_TRACE") != nullptr;
+    if (trace) std::fprintf(stderr, "[xmca jacobi] n=%d NT=%d cplx=%d sweep %d: max off/scale seen = %.3e\n", n, NT, (int)CPLX, sweeps, off);
     if (S == 1 || !(off >= tol) || !std::isfinite(off)) break;
   }
   XMCA_CHECK(std::isfinite(off), XMCA_ERR_NUMERIC, "SVD failed. NaN entries may be the problem.");

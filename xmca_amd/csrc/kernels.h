@@ -71,6 +71,23 @@ __global__ void circulant_kernel(const double* __restrict__ col, int T, TO* __re
   }
 }
 
+// Orthonormal Fourier vectors of the frequencies kept by the analytic signal: Phi[t][f] = exp(2 pi i f t / T) / sqrt(T),
+// f = 0 .. m-1 (m = T/2 + 1 for even T, (T+1)/2 for odd T), and the Hilbert weights h_f of scipy.signal.hilbert
+// (1 for DC and Nyquist, 2 otherwise), so that hilbert(x) = Phi diag(h) Phi^H x.
+__global__ void fourier_basis_kernel(int T, int m, double* __restrict__ Pr, double* __restrict__ Pi, double* __restrict__ hvec) {
+  const int64_t n = (int64_t)T * m;
+  const double inv = 1.0 / sqrt((double)T);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int t = (int)(i / m), f = (int)(i % m);
+    const int64_t ft = ((int64_t)f * t) % T;
+    double sn, cs;
+    sincospi(2.0 * (double)ft / (double)T, &sn, &cs);
+    Pr[i] = cs * inv;
+    Pi[i] = sn * inv;
+    if (i < m) hvec[i] = (i == 0 || (T % 2 == 0 && i == T / 2)) ? 1.0 : 2.0;
+  }
+}
+
 __global__ void sqrt_clamp_kernel(const double* __restrict__ lam, double* __restrict__ s, int n, double scale) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) s[i] = sqrt(fmax(lam[i] * scale, 0.0));

@@ -95,16 +95,12 @@ __global__ void rot_import_loadings_kernel(const double* __restrict__ L, int64_t
 //   MODE 3 (column max)  : X as in MODE 2; colmax_k = max_n |X_nk|  (atomicMax on the bit pattern)
 // partial results: part[wg * p * p + j * p + k]  (planes)
 template <bool CPLX, int MODE, int SEL>
-__global__ __launch_bounds__(256) void rot_accum_kernel(const double* __restrict__ Ar, const double* __restrict__ Ai,
-                                                        const double* __restrict__ h, int64_t N, int64_t Nleft, int p,
-                                                        const double* __restrict__ Rr, const double* __restrict__ Ri,
-                                                        const double* __restrict__ cvec, const double* __restrict__ colmax,
-                                                        double power, const double* __restrict__ state,
-                                                        double* __restrict__ part_r, double* __restrict__ part_i,
-                                                        unsigned long long* __restrict__ colmax_bits) {
-  if (MODE == 0 && (state[1] != 0.0 || state[4] != 0.0)) return;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  double* sm = reinterpret_cast<double*>(smem_raw);
+__device__ __forceinline__ void rot_accum_body(double* __restrict__ sm, const double* __restrict__ Ar, const double* __restrict__ Ai,
+                                               const double* __restrict__ h, int64_t N, int64_t Nleft, int p,
+                                               const double* __restrict__ Rr, const double* __restrict__ Ri,
+                                               const double* __restrict__ cvec, const double* __restrict__ colmax, double power,
+                                               double* __restrict__ part_r, double* __restrict__ part_i,
+                                               unsigned long long* __restrict__ colmax_bits) {
   // layout: Xs[p][LDP], Ys[p][LDP], Rs[p][p]  (x2 planes when complex), wgt[PB]
   const int pl = p * ROT_LDP;
   double* Xr = sm;
@@ -265,6 +261,20 @@ __global__ __launch_bounds__(256) void rot_accum_kernel(const double* __restrict
       if constexpr (CPLX) part_i[idx] = acci[sl];
     }
   }
+}
+
+template <bool CPLX, int MODE, int SEL>
+__global__ __launch_bounds__(256) void rot_accum_kernel(const double* __restrict__ Ar, const double* __restrict__ Ai,
+                                                        const double* __restrict__ h, int64_t N, int64_t Nleft, int p,
+                                                        const double* __restrict__ Rr, const double* __restrict__ Ri,
+                                                        const double* __restrict__ cvec, const double* __restrict__ colmax,
+                                                        double power, const double* __restrict__ state,
+                                                        double* __restrict__ part_r, double* __restrict__ part_i,
+                                                        unsigned long long* __restrict__ colmax_bits) {
+  if (MODE == 0 && (state[1] != 0.0 || state[4] != 0.0)) return;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  rot_accum_body<CPLX, MODE, SEL>(reinterpret_cast<double*>(smem_raw), Ar, Ai, h, N, Nleft, p, Rr, Ri, cvec, colmax, power, part_r,
+                                  part_i, colmax_bits);
 }
 
 static inline size_t rot_accum_smem(int p, bool cplx) {
@@ -567,6 +577,227 @@ __global__ __launch_bounds__(256) void varimax_step_kernel(const double* __restr
     if (!(d == d)) state[4] = 1.0;                          // NaN (e.g. a zero row in the loadings)
     else if (fabs(d - d_old) / d < tol) state[1] = 1.0;     // rotation.py:62
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// One whole Varimax iteration in ONE launch: every workgroup accumulates its partial G (rot_accum_body<0>), the
+// workgroup that arrives last (agent-scope release / ticket / acquire, cdna_hip_programming.md G16) reduces the
+// partials in a fixed order and finishes the step.  R = U V^H is the unitary polar factor of G, obtained by the
+// Newton-Schulz iteration X <- X (1.5 I - 0.5 X^H X) from X0 = G / ||G||_F (only p x p products; quadratic
+// convergence; 11-20 iterations for cond(G) <= 1e4), and d = sum(s) = Re tr(R^H G) - first-order insensitive to
+// errors in R because R^H dR is skew-Hermitian.  Same R and d as rotation.py:59-61 to rounding, no SVD.
+// ---------------------------------------------------------------------------------------------------------------
+static inline size_t rot_polar_smem(int p, bool cplx) { return sizeof(double) * ((cplx ? 2 : 1) * 4 * (size_t)p * p + 1024); }
+
+template <bool CPLX>
+__device__ void varimax_polar_step(double* __restrict__ sm, const double* __restrict__ part_r, const double* __restrict__ part_i,
+                                   int nwg, int p, const double* __restrict__ A0r, const double* __restrict__ A0i,
+                                   double* __restrict__ Rr, double* __restrict__ Ri, double* __restrict__ cvec,
+                                   double* __restrict__ state, double tol) {
+  const int tid = threadIdx.x, pp = p * p;
+  double* Gr = sm;            // G, later A0 R
+  double* Xr = Gr + pp;
+  double* Tr = Xr + pp;
+  double* Yr = Tr + pp;
+  double* scr = Yr + pp;      // 1024 doubles of scratch
+  double* Gi = scr + 1024;
+  double* Xi = Gi + pp;
+  double* Ti = Xi + pp;
+  double* Yi = Ti + pp;
+  auto block_reduce = [&](double v, bool take_max) -> double {
+    for (int o = 32; o > 0; o >>= 1) {
+      const double w = __shfl_xor(v, o);
+      v = take_max ? fmax(v, w) : v + w;
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) scr[1000 + (tid >> 6)] = v;
+    __syncthreads();
+    const double a = scr[1000], b = scr[1001], c = scr[1002], d = scr[1003];
+    return take_max ? fmax(fmax(a, b), fmax(c, d)) : (a + b) + (c + d);
+  };
+
+  // G = sum of partials (fixed order): pp <= 128 uses 256 / pp thread slices per entry
+  const int nsl = pp <= 128 ? 256 / pp : 1;
+  if (nsl > 1) {
+    const int sl = tid / pp, e = tid % pp;
+    if (sl < nsl) {
+      // 8 loads in flight per thread (the partials sit in L2; a dependent chain would cost ~1 us per load)
+      double ar[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ai[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int w = sl; w < nwg; w += 8 * nsl) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int ww = w + u * nsl;
+          if (ww < nwg) {
+            ar[u] += part_r[(int64_t)ww * pp + e];
+            if constexpr (CPLX) ai[u] += part_i[(int64_t)ww * pp + e];
+          }
+        }
+      }
+      scr[tid] = ((ar[0] + ar[1]) + (ar[2] + ar[3])) + ((ar[4] + ar[5]) + (ar[6] + ar[7]));
+      if constexpr (CPLX) scr[256 + tid] = ((ai[0] + ai[1]) + (ai[2] + ai[3])) + ((ai[4] + ai[5]) + (ai[6] + ai[7]));
+    }
+    __syncthreads();
+  }
+  double fro2 = 0.0;
+  for (int e = tid; e < pp; e += 256) {
+    double sr = 0.0, si = 0.0;
+    if (nsl > 1) {
+      for (int sl = 0; sl < nsl; ++sl) {
+        sr += scr[sl * pp + e];
+        if constexpr (CPLX) si += scr[256 + sl * pp + e];
+      }
+    } else {
+      for (int w = 0; w < nwg; ++w) {
+        sr += part_r[(int64_t)w * pp + e];
+        if constexpr (CPLX) si += part_i[(int64_t)w * pp + e];
+      }
+    }
+    Gr[e] = sr;
+    fro2 += sr * sr;
+    if constexpr (CPLX) { Gi[e] = si; fro2 += si * si; }
+  }
+  fro2 = block_reduce(fro2, false);
+  const double inv = 1.0 / sqrt(fro2);
+  for (int e = tid; e < pp; e += 256) {
+    Xr[e] = Gr[e] * inv;
+    if constexpr (CPLX) Xi[e] = Gi[e] * inv;
+  }
+  __syncthreads();
+
+  // Newton-Schulz with two barriers per iteration: X and Y alternate roles (no copy), the convergence measure of
+  // iteration k is reduced per wave and read by everybody after the barrier that also publishes T.
+  int it = 0;
+  bool ok = false;
+  double* Cr = Xr;   // current iterate
+  double* Ci = Xi;
+  double* Nr = Yr;   // next iterate
+  double* Ni = Yi;
+  for (; it < 100; ++it) {
+    double err = 0.0;
+    for (int e = tid; e < pp; e += 256) {
+      const int j = e / p, k = e % p;
+      double tr = 0.0, ti = 0.0;
+      for (int m = 0; m < p; ++m) {
+        const double ar = Cr[m * p + j], br = Cr[m * p + k];
+        tr += ar * br;
+        if constexpr (CPLX) {
+          const double ai = Ci[m * p + j], bi = Ci[m * p + k];
+          tr += ai * bi;                 // conj(a) b
+          ti += ar * bi - ai * br;
+        }
+      }
+      Tr[e] = tr;
+      if constexpr (CPLX) Ti[e] = ti;
+      err = fmax(err, fmax(fabs(tr - (j == k ? 1.0 : 0.0)), fabs(ti)));
+      if (!(tr == tr)) err = HUGE_VAL;
+    }
+    for (int o = 32; o > 0; o >>= 1) err = fmax(err, __shfl_xor(err, o));
+    if ((tid & 63) == 0) scr[1000 + 4 * (it & 1) + (tid >> 6)] = err;
+    __syncthreads();
+    {
+      const double* e4 = scr + 1000 + 4 * (it & 1);
+      err = fmax(fmax(e4[0], e4[1]), fmax(e4[2], e4[3]));
+    }
+    if (!(err < HUGE_VAL)) break;        // NaN / inf
+    if (err < 1e-14) { ok = true; break; }
+    for (int e = tid; e < pp; e += 256) {
+      const int j = e / p, k = e % p;
+      double yr = 0.0, yi = 0.0;
+      for (int m = 0; m < p; ++m) {
+        const double xr = Cr[j * p + m], t_r = Tr[m * p + k];
+        yr += xr * t_r;
+        if constexpr (CPLX) {
+          const double xi = Ci[j * p + m], t_i = Ti[m * p + k];
+          yr -= xi * t_i;
+          yi += xr * t_i + xi * t_r;
+        }
+      }
+      Nr[e] = 1.5 * Cr[e] - 0.5 * yr;
+      if constexpr (CPLX) Ni[e] = 1.5 * Ci[e] - 0.5 * yi;
+    }
+    __syncthreads();
+    { double* t = Cr; Cr = Nr; Nr = t; }
+    { double* t = Ci; Ci = Ni; Ni = t; }
+  }
+  if (Cr != Xr) {   // the tail below expects the converged factor in X
+    for (int e = tid; e < pp; e += 256) {
+      Xr[e] = Cr[e];
+      if constexpr (CPLX) Xi[e] = Ci[e];
+    }
+  }
+  __syncthreads();
+
+  // d = Re tr(R^H G);  R -> global;  T <- A0 (staging);  c_k = Re sum_j conj(R[j][k]) (A0 R)[j][k]
+  double dsum = 0.0;
+  for (int e = tid; e < pp; e += 256) {
+    dsum += Xr[e] * Gr[e];
+    if constexpr (CPLX) dsum += Xi[e] * Gi[e];
+    Rr[e] = Xr[e];
+    Tr[e] = A0r[e];
+    if constexpr (CPLX) { Ri[e] = Xi[e]; Ti[e] = A0i[e]; }
+  }
+  dsum = block_reduce(dsum, false);
+  for (int e = tid; e < pp; e += 256) {
+    const int j = e / p, k = e % p;
+    double tr = 0.0, ti = 0.0;
+    for (int l = 0; l < p; ++l) {
+      const double ar = Tr[j * p + l], rr = Xr[l * p + k];
+      tr += ar * rr;
+      if constexpr (CPLX) {
+        const double ai = Ti[j * p + l], ri = Xi[l * p + k];
+        tr -= ai * ri;
+        ti += ar * ri + ai * rr;
+      }
+    }
+    double prod = Xr[e] * tr;
+    if constexpr (CPLX) prod += Xi[e] * ti;
+    Yr[e] = prod;
+  }
+  __syncthreads();
+  for (int k = tid; k < p; k += 256) {
+    double acc = 0.0;
+    for (int j = 0; j < p; ++j) acc += Yr[j * p + k];
+    cvec[k] = acc;
+  }
+  if (tid == 0) {
+    const double d_old = state[2];
+    state[3] = d_old;
+    state[2] = dsum;
+    state[0] += 1.0;
+    state[5] = (double)it;
+    if (!ok || !(dsum == dsum)) state[4] = 1.0;                  // NaN / singular G
+    else if (fabs(dsum - d_old) / dsum < tol) state[1] = 1.0;    // rotation.py:62
+  }
+}
+
+template <bool CPLX>
+__global__ __launch_bounds__(256) void varimax_iter_kernel(const double* __restrict__ Ar, const double* __restrict__ Ai,
+                                                           const double* __restrict__ h, int64_t N, int p,
+                                                           const double* __restrict__ A0r, const double* __restrict__ A0i,
+                                                           double* Rr, double* Ri, double* cvec, double* state, double* part_r,
+                                                           double* part_i, unsigned int* counter, double tol) {
+  if (state[1] != 0.0 || state[4] != 0.0) return;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* sm = reinterpret_cast<double*>(smem_raw);
+  rot_accum_body<CPLX, 0, 0>(sm, Ar, Ai, h, N, N, p, Rr, Ri, cvec, nullptr, 1.0, part_r, part_i, nullptr);
+  // publish the partial, take a ticket (release before, acquire after: placement independent)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  __shared__ int is_last;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned int t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (t == gridDim.x - 1);
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    is_last = last;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  varimax_polar_step<CPLX>(sm, part_r, part_i, (int)gridDim.x, p, A0r, A0i, Rr, Ri, cvec, state, tol);
 }
 
 // B[n][k] = scale_n * sum_j a_j(n) M[j][k]   ->  N x p row-major (interleaved complex) for the host

@@ -22,6 +22,8 @@ struct xmca_handle {
   bool field_set[2] = {false, false};
   SolveResult res;
   bool solved = false;
+  bool hilbert_pending = false;          // complexify requested; carried out (or folded into the solve) lazily
+  std::vector<double> hilbert_col;
   RotationDevice rot;
 };
 
@@ -138,6 +140,16 @@ void complexify_impl(xmca_handle* h, const double* col_host) {
 template <typename TI>
 void solve_impl(xmca_handle* h, int n_fields, int64_t n_vec) {
   FieldData<TI>* f = fields_of<TI>(h);
+  if (h->hilbert_pending) {
+    static const bool analytic_on = [] { const char* e = std::getenv("XMCA_ANALYTIC"); return !(e && e[0] == '0'); }();
+    if (analytic_on && Solver<TI>::analytic_applicable(f, n_fields)) {
+      Solver<TI> s(h->st, h->gws, h->ews, h->tm);
+      s.solve_analytic(f, n_fields, (int)n_vec, h->res);
+      return;
+    }
+    complexify_impl<TI>(h, h->hilbert_col.data());
+    h->hilbert_pending = false;
+  }
   const bool cplx = f[0].has_im;
   if (n_fields == 2) XMCA_CHECK(f[1].has_im == cplx, XMCA_ERR_INVALID, "solve: both fields must be real or both complex");
   Solver<TI> s(h->st, h->gws, h->ews, h->tm);
@@ -191,7 +203,9 @@ void rule_n_impl(xmca_handle* h, int64_t T, int64_t Nx, int64_t Ny, int n_fields
   const int64_t Ns[2] = {Nx, Ny};
   DevBuf<TI> htb;
   const bool cplx = ht_host != nullptr;
-  if (cplx) build_hilbert<TI>(h, ht_host, T, htb);
+  static const bool analytic_on = [] { const char* e = std::getenv("XMCA_ANALYTIC"); return !(e && e[0] == '0'); }();
+  const bool analytic = cplx && analytic_on && Nx > T && (n_fields == 1 || Ny > T);
+  if (cplx && !analytic) build_hilbert<TI>(h, ht_host, T, htb);
   struct { const TI* r; } ht{htb.get()};
   Solver<TI> solver(h->st, h->gws, h->ews, h->tm);
   Rotator rot(h->st, h->tm);
@@ -210,14 +224,15 @@ void rule_n_impl(xmca_handle* h, int64_t T, int64_t Nx, int64_t Ny, int n_fields
                          (uint32_t)s);
       hipLaunchKernelGGL((center_columns_kernel<TI>), dim3(ceil_div(Ns[s], 256)), dim3(256), 0, h->st, x, (int)T, Ns[s]);
       XMCA_HIP(hipGetLastError());
-      if (cplx) {
+      if (cplx && !analytic) {
         GemmOpts o;
         gemm<TI, TI>(h->st, h->gws, ht.r, T, x, Ns[s], f[s].im.ensure((size_t)n), Ns[s], (int)T, (int)Ns[s], (int)T, o);
         f[s].has_im = true;
       }
     }
     h->tm.end();
-    solver.solve(f, n_fields, cplx, rotated ? p : 0, res);
+    if (analytic) solver.solve_analytic(f, n_fields, rotated ? p : 0, res);
+    else solver.solve(f, n_fields, cplx, rotated ? p : 0, res);
     double* out = spectra + (run - run_begin) * n_out;
     kept[run - run_begin] = 1;
     if (!rotated) {
@@ -306,14 +321,16 @@ int xmca_set_field(xmca_handle* h, int side, const void* re, const void* im, int
   else set_field_impl<double>(h, side, re, im, T, N, location);
   h->field_set[side] = true;
   h->solved = false;
+  if (side == 0) h->hilbert_pending = false;
   API_END(h)
 }
 
 int xmca_complexify(xmca_handle* h, const double* hilbert_col) {
   API_BEGIN(h)
   XMCA_CHECK(h->field_set[0] && hilbert_col, XMCA_ERR_STATE, "complexify: set a field first");
-  if (h->dtype == XMCA_F32) complexify_impl<float>(h, hilbert_col);
-  else complexify_impl<double>(h, hilbert_col);
+  const int64_t T = h->dtype == XMCA_F32 ? h->f32[0].T : h->f64[0].T;
+  h->hilbert_col.assign(hilbert_col, hilbert_col + T);
+  h->hilbert_pending = true;      // xmca_solve decides: subspace formulation (no imaginary plane) or X_im = Ht X
   h->solved = false;
   API_END(h)
 }
@@ -515,40 +532,40 @@ int xmca_eigh(xmca_handle* h, const double* A, int n, int is_complex, double* la
 int xmca_bench_gram(xmca_handle* h, int side, int reps, double* avg_ms, double* kernel_ms, double* flops) {
   API_BEGIN(h)
   XMCA_CHECK((side == 0 || side == 1) && h->field_set[side] && reps >= 1, XMCA_ERR_STATE, "bench_gram: field not set");
-  hipEvent_t e0, e1;
-  XMCA_HIP(hipEventCreate(&e0));
-  XMCA_HIP(hipEventCreate(&e1));
   int64_t T, N;
-  DevBuf<double> G;
-  auto run = [&](int force_splits, bool kernel_only, int n) {
-    GemmOpts o;
-    o.b_nfast = false; o.upper_only = true; o.mirror = 1; o.force_splits = force_splits;
-    (void)kernel_only;
-    for (int i = 0; i < n; ++i) {
-      if (h->dtype == XMCA_F32)
-        gemm<float, double>(h->st, h->gws, h->f32[side].r(), N, h->f32[side].r(), N, G.get(), T, (int)T, (int)T, (int)N, o);
-      else
-        gemm<double, double>(h->st, h->gws, h->f64[side].r(), N, h->f64[side].r(), N, G.get(), T, (int)T, (int)T, (int)N, o);
-    }
-  };
   if (h->dtype == XMCA_F32) { T = h->f32[side].T; N = h->f32[side].N; } else { T = h->f64[side].T; N = h->f64[side].N; }
+  DevBuf<double> G;
   G.ensure((size_t)T * T);
-  run(0, false, 1);   // warm-up
+  std::vector<hipEvent_t> ev(2 * (size_t)reps + 2);
+  for (auto& e : ev) XMCA_HIP(hipEventCreate(&e));
+  auto run = [&](hipEvent_t b, hipEvent_t e) {
+    GemmOpts o;
+    o.b_nfast = false; o.upper_only = true; o.mirror = 1; o.ev_begin = b; o.ev_end = e;
+    if (h->dtype == XMCA_F32)
+      gemm<float, double>(h->st, h->gws, h->f32[side].r(), N, h->f32[side].r(), N, G.get(), T, (int)T, (int)T, (int)N, o);
+    else
+      gemm<double, double>(h->st, h->gws, h->f64[side].r(), N, h->f64[side].r(), N, G.get(), T, (int)T, (int)T, (int)N, o);
+  };
+  run(nullptr, nullptr);   // warm-up
   XMCA_HIP(hipStreamSynchronize(h->st));
+  XMCA_HIP(hipEventRecord(ev[2 * reps], h->st));
+  for (int i = 0; i < reps; ++i) run(ev[2 * i], ev[2 * i + 1]);
+  XMCA_HIP(hipEventRecord(ev[2 * reps + 1], h->st));
+  XMCA_HIP(hipEventSynchronize(ev[2 * reps + 1]));
   float ms = 0.f;
-  XMCA_HIP(hipEventRecord(e0, h->st));
-  run(0, false, reps);
-  XMCA_HIP(hipEventRecord(e1, h->st));
-  XMCA_HIP(hipEventSynchronize(e1));
-  XMCA_HIP(hipEventElapsedTime(&ms, e0, e1));
+  XMCA_HIP(hipEventElapsedTime(&ms, ev[2 * reps], ev[2 * reps + 1]));
+  double kms = 0.0;
+  for (int i = 0; i < reps; ++i) {
+    float t = 0.f;
+    XMCA_HIP(hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]));
+    kms += t;
+  }
   if (avg_ms) *avg_ms = ms / reps;
-  if (kernel_ms) *kernel_ms = ms / reps;
+  if (kernel_ms) *kernel_ms = kms / reps;
   if (flops) *flops = (double)T * (double)(T + 1) * (double)N;
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
+  for (auto& e : ev) (void)hipEventDestroy(e);
   API_END(h)
 }
-
 
 int xmca_bench_gemm(xmca_handle* h, int M, int N, int K, int dtype, int a_kfast, int b_nfast, int upper_only, int splits,
                     int reps, double* avg_ms) {
