@@ -121,3 +121,37 @@ def test_errors(hip):
     with pytest.raises(np.linalg.LinAlgError):        # array.py:575-578
         h.solve(1)
     h.close()
+
+
+def test_analytic_subspace_path_equals_general_path(hip, monkeypatch):
+    """complexify on wide fields uses the T/2-dimensional Fourier subspace (no imaginary plane on the device); with
+    XMCA_ANALYTIC=0 the same model goes through X_im = Ht X and T x T eigenproblems: identical sigma and vectors."""
+    import subprocess, sys, json, os
+    fields = make_input("wide_both")
+    rank, sig, V = device_solve(hip, fields, True)
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r);"
+            "from golden_inputs import make_input; from oracle import ref_numpy as O; from xmca_amd import _hip;"
+            "h = _hip.Handle(0); f = [O.flatten_and_center(x)[0] for x in make_input('wide_both')];"
+            "[h.set_field(s, x) for s, x in enumerate(f)]; h.complexify(f[0].shape[0]); r = h.solve(2);"
+            "s = h.singular_values(r); v = h.vectors(0, 8, f[0].shape[1], f[0].dtype);"
+            "print(json.dumps({'s': s.tolist(), 'vr': v.real.tolist(), 'vi': v.imag.tolist(), 'info': h.solve_info()}))"
+            ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, XMCA_ANALYTIC="0")
+    out = json.loads(subprocess.run([sys.executable, "-c", code], env=env, check=True, capture_output=True, text=True).stdout)
+    s_gen = np.array(out["s"])
+    v_gen = (np.array(out["vr"]) + 1j * np.array(out["vi"])).T
+    T = 64
+    m = T // 2 + 1
+    assert hip.solve_info()[0]["slots"] < out["info"][0]["slots"]            # smaller eigenproblem
+    keep = s_gen > 1e-9 * s_gen[0]
+    assert np.max(np.abs(sig[keep] - s_gen[keep]) / s_gen[keep]) < 1e-9
+    assert np.all(sig[m:] == 0.0)                                            # null modes are exact zeros
+    mine, _ = align_modes(V[0][:, :8], v_gen)
+    assert np.max(np.abs(mine - v_gen)) < 1e-8
+
+
+def test_values_only_solve(hip):
+    fields = make_input("wide_left")
+    rank, sig, V = device_solve(hip, fields, False, n_vec=0)
+    rank2, sig2, _ = device_solve(hip, fields, False)
+    assert V[0].shape[1] == 0 and np.allclose(sig, sig2, rtol=1e-12, atol=0)

@@ -287,7 +287,15 @@ __host__ __device__ inline void jacobi_next_diag_pair(int Pn, int S, int& A, int
   A = Pn - 1; B = Pn + 1;
 }
 
-constexpr int JAC_ZW = 4;   // eigenvector tiles (NT x NT) handled per workgroup, sharing one J_P
+#ifndef XMCA_JAC_ZW
+#define XMCA_JAC_ZW 4
+#endif
+constexpr int JAC_ZW = XMCA_JAC_ZW;   // eigenvector tiles (NT x NT) handled per workgroup, sharing one J_P
+#ifdef XMCA_JAC_NT_STORE
+#define JAC_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define JAC_STORE(ptr, val) (*(ptr) = (val))
+#endif
 
 // One round of the two-sided update:  G'[P,Q] = J_P^H G[P,Q] J_Q (upper tiles + mirrored write),
 // Z'[P,c] = J_P^H Z[P,c], both written to the slots of the next round.
@@ -442,8 +450,8 @@ __device__ __forceinline__ void jacobi_update_body(JacUpdSmem<NT, CPLX>& sm, con
         const int e = tid + 256 * i, r = e / NT, c = e % NT;
         const int dr = jacobi_dest_block(P, r / HB, S) * HB + r % HB;
         const int64_t o = (int64_t)dr * ld + (int64_t)Qc * NT + c;
-        Zr_out[o] = Br[r][c];
-        if constexpr (CPLX) Zi_out[o] = Bi[r][c];
+        JAC_STORE(&Zr_out[o], Br[r][c]);
+        if constexpr (CPLX) JAC_STORE(&Zi_out[o], Bi[r][c]);
       }
       __syncthreads();   // the next sub-tile overwrites B
       continue;
@@ -490,14 +498,14 @@ __device__ __forceinline__ void jacobi_update_body(JacUpdSmem<NT, CPLX>& sm, con
       const int e = tid + 256 * i, r = e / NT, c = e % NT;
       const int dr = jacobi_dest_block(P, r / HB, S) * HB + r % HB;
       const int dc = jacobi_dest_block(Q, c / HB, S) * HB + c % HB;
-      Gr_out[(int64_t)dr * ld + dc] = Br[r][c];
-      if constexpr (CPLX) Gi_out[(int64_t)dr * ld + dc] = Bi[r][c];
+      JAC_STORE(&Gr_out[(int64_t)dr * ld + dc], Br[r][c]);
+      if constexpr (CPLX) JAC_STORE(&Gi_out[(int64_t)dr * ld + dc], Bi[r][c]);
       // mirrored element: this thread now plays (row' = c-index, col' = r-index) with r fastest
       const int r2 = e % NT, c2 = e / NT;
       const int dr2 = jacobi_dest_block(P, r2 / HB, S) * HB + r2 % HB;
       const int dc2 = jacobi_dest_block(Q, c2 / HB, S) * HB + c2 % HB;
-      Gr_out[(int64_t)dc2 * ld + dr2] = Br[r2][c2];
-      if constexpr (CPLX) Gi_out[(int64_t)dc2 * ld + dr2] = -Bi[r2][c2];
+      JAC_STORE(&Gr_out[(int64_t)dc2 * ld + dr2], Br[r2][c2]);
+      if constexpr (CPLX) JAC_STORE(&Gi_out[(int64_t)dc2 * ld + dr2], -Bi[r2][c2]);
     }
   }
 }

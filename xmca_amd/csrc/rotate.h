@@ -647,10 +647,18 @@ __device__ void varimax_polar_step(double* __restrict__ sm, const double* __rest
         if constexpr (CPLX) si += scr[256 + sl * pp + e];
       }
     } else {
-      for (int w = 0; w < nwg; ++w) {
-        sr += part_r[(int64_t)w * pp + e];
-        if constexpr (CPLX) si += part_i[(int64_t)w * pp + e];
+      double ar[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ai[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int w = 0; w < nwg; w += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (w + u < nwg) {
+            ar[u] += part_r[(int64_t)(w + u) * pp + e];
+            if constexpr (CPLX) ai[u] += part_i[(int64_t)(w + u) * pp + e];
+          }
+        }
       }
+      sr = ((ar[0] + ar[1]) + (ar[2] + ar[3])) + ((ar[4] + ar[5]) + (ar[6] + ar[7]));
+      si = ((ai[0] + ai[1]) + (ai[2] + ai[3])) + ((ai[4] + ai[5]) + (ai[6] + ai[7]));
     }
     Gr[e] = sr;
     fro2 += sr * sr;

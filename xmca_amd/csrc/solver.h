@@ -728,6 +728,10 @@ class Rotator {
       launched += batch;
       XMCA_HIP(hipMemcpyAsync(state, d.state.get(), sizeof(state), hipMemcpyDeviceToHost, st));
       XMCA_HIP(hipStreamSynchronize(st));
+      static const bool trace = std::getenv("XMCA_ROT_TRACE") != nullptr;
+      if (trace)
+        std::fprintf(stderr, "[xmca varimax] p=%d N=%lld cplx=%d launched=%d iter=%g conv=%g d=%.12g polar_its=%g nan=%g\n", p,
+                     (long long)d.N, (int)CPLX, launched, state[0], state[1], state[2], state[5], state[4]);
       if (state[1] != 0.0 || state[4] != 0.0) break;
     }
     tm.end();
