@@ -142,7 +142,7 @@ def test_analytic_subspace_path_equals_general_path(hip, monkeypatch):
     v_gen = (np.array(out["vr"]) + 1j * np.array(out["vi"])).T
     T = 64
     m = T // 2 + 1
-    assert hip.solve_info()[0]["slots"] < out["info"][0]["slots"]            # smaller eigenproblem
+    assert hip.solve_info()[0]["slots"] <= out["info"][0]["slots"]           # never a larger eigenproblem (33 vs 64 here)
     keep = s_gen > 1e-9 * s_gen[0]
     assert np.max(np.abs(sig[keep] - s_gen[keep]) / s_gen[keep]) < 1e-9
     assert np.all(sig[m:] == 0.0)                                            # null modes are exact zeros

@@ -95,7 +95,7 @@ struct JacUpdSmem {
   double Ai[CPLX ? NT : 1][CPLX ? NT + 1 : 1], Bi[CPLX ? NT : 1][CPLX ? NT + 1 : 1];
 };
 
-template <int NT, bool CPLX>
+template <int NT, bool CPLX, bool PRELOADED = false>
 __device__ __forceinline__ void jacobi_tile_evd_body(JacTileSmem<NT, CPLX>& sm, const int P, const double* __restrict__ Gr,
                                                      const double* __restrict__ Gi, int ld, double* __restrict__ Jr,
                                                      double* __restrict__ Ji, double* __restrict__ Dr, double* __restrict__ Di,
@@ -116,17 +116,19 @@ __device__ __forceinline__ void jacobi_tile_evd_body(JacTileSmem<NT, CPLX>& sm, 
 
   const int tid = threadIdx.x;
   const double gscale = scal[0], abs_floor = scal[1];
-  const int64_t base = (int64_t)P * NT * ld + (int64_t)P * NT;
-  for (int e = tid; e < NT * NT; e += 256) {
-    const int i = e / NT, j = e % NT;
-    Mr[i][j] = Gr[base + (int64_t)i * ld + j];
-    Vr[i][j] = (i == j) ? 1.0 : 0.0;
-    if constexpr (CPLX) {
-      Mi[i][j] = Gi[base + (int64_t)i * ld + j];
-      Vi[i][j] = 0.0;
+  if constexpr (!PRELOADED) {
+    const int64_t base = (int64_t)P * NT * ld + (int64_t)P * NT;
+    for (int e = tid; e < NT * NT; e += 256) {
+      const int i = e / NT, j = e % NT;
+      Mr[i][j] = Gr[base + (int64_t)i * ld + j];
+      Vr[i][j] = (i == j) ? 1.0 : 0.0;
+      if constexpr (CPLX) {
+        Mi[i][j] = Gi[base + (int64_t)i * ld + j];
+        Vi[i][j] = 0.0;
+      }
     }
+    __syncthreads();
   }
-  __syncthreads();
 
   // off-diagonal measure of this tile before it is touched (drives the outer sweep loop)
   {
@@ -510,6 +512,135 @@ __device__ __forceinline__ void jacobi_update_body(JacUpdSmem<NT, CPLX>& sm, con
   }
 }
 
+// The two half-blocks that form pair slot Pn in the NEXT round: (A, hA) becomes its top, (B, hB) its bottom half
+// (inverse of jacobi_dest_block; S >= 3).
+__host__ __device__ inline void jacobi_next_diag_halves(int Pn, int S, int& A, int& hA, int& B, int& hB) {
+  if (Pn == 0) { A = 0; hA = 0; B = 1; hB = 1; }
+  else if (Pn == S - 1) { A = S - 2; hA = 0; B = S - 1; hB = 0; }
+  else if (Pn == 1) { A = 0; hA = 1; B = 2; hB = 1; }
+  else { A = Pn - 1; hA = 0; B = Pn + 1; hB = 1; }
+}
+
+// Builds, in LDS, the diagonal tile that pair slot Pn will hold in the next round - without waiting for the update of
+// the current round to be written: its diagonal quarters are quarters of the transformed diagonal tiles D_A, D_B of
+// this round and its off-diagonal quarter is the (hA, hB) quarter of J_A^H G[A,B] J_B, recomputed here (1/3 of a tile
+// update).  This removes the separate "head" launch from every round.
+template <int NT, bool CPLX>
+__device__ __forceinline__ void jacobi_assemble_next_diag(JacTileSmem<NT, CPLX>& st, JacUpdSmem<NT, CPLX>& su, const int Pn, const int S,
+                                                          const double* __restrict__ Gr_in, const double* __restrict__ Gi_in,
+                                                          const int ld, const double* __restrict__ Jr, const double* __restrict__ Ji,
+                                                          const double* __restrict__ Dr, const double* __restrict__ Di) {
+  constexpr int HB = NT / 2;
+  constexpr int XT = (HB / 16) * (NT / 16);     // MFMA tiles of X (HB x NT): 8 or 2
+  constexpr int XPW = (XT + 3) / 4;             // per wave: 2 or 1
+  constexpr int YT = (HB / 16) * (HB / 16);     // MFMA tiles of Yq (HB x HB): 4 or 1
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+  int A, hA, B, hB;
+  jacobi_next_diag_halves(Pn, S, A, hA, B, hB);
+  const int64_t ja = (int64_t)A * NT * NT, jb = (int64_t)B * NT * NT;
+  const int64_t tbase = (int64_t)A * NT * ld + (int64_t)B * NT;
+  for (int e = tid; e < NT * NT; e += 256) {
+    const int r = e / NT, c = e % NT;
+    su.Ar[r][c] = Jr[ja + e];
+    su.Br[r][c] = Gr_in[tbase + (int64_t)r * ld + c];
+    if constexpr (CPLX) {
+      su.Ai[r][c] = Ji[ja + e];
+      su.Bi[r][c] = Gi_in[tbase + (int64_t)r * ld + c];
+    }
+  }
+  __syncthreads();
+  // X = J_A[:, hA]^H T      (HB x NT)
+  d4_t xr[XPW], xi[CPLX ? XPW : 1];
+#pragma unroll
+  for (int a = 0; a < XPW; ++a) {
+    const int t = wave * XPW + a;
+    d4_t ar = {0, 0, 0, 0}, ai = {0, 0, 0, 0};
+    if (t < XT) {
+      const int ti = t / (NT / 16), tj = t % (NT / 16);
+      for (int k0 = 0; k0 < NT; k0 += 4) {
+        const int k = k0 + l4;
+        const double jr = su.Ar[k][hA * HB + ti * 16 + l15];
+        const double tr = su.Br[k][tj * 16 + l15];
+        ar = Mfma<double>::mma(jr, tr, ar);
+        if constexpr (CPLX) {
+          const double ji = su.Ai[k][hA * HB + ti * 16 + l15];
+          const double tim = su.Bi[k][tj * 16 + l15];
+          ar = Mfma<double>::mma(ji, tim, ar);
+          ai = Mfma<double>::mma(jr, tim, ai);
+          ai = Mfma<double>::mma(-ji, tr, ai);
+        }
+      }
+    }
+    xr[a] = ar;
+    if constexpr (CPLX) xi[a] = ai;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < XPW; ++a) {
+    const int t = wave * XPW + a;
+    if (t < XT) {
+      const int ti = t / (NT / 16), tj = t % (NT / 16);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = ti * 16 + Mfma<double>::row(lane, r), col = tj * 16 + l15;
+        su.Br[row][col] = xr[a][r];
+        if constexpr (CPLX) su.Bi[row][col] = xi[a][r];
+      }
+    }
+  }
+  for (int e = tid; e < NT * NT; e += 256) {
+    su.Ar[e / NT][e % NT] = Jr[jb + e];
+    if constexpr (CPLX) su.Ai[e / NT][e % NT] = Ji[jb + e];
+  }
+  __syncthreads();
+  // Yq = X J_B[:, hB]      (HB x HB), one MFMA tile per wave
+  d4_t yr = {0, 0, 0, 0}, yi = {0, 0, 0, 0};
+  const int yti = wave / (HB / 16), ytj = wave % (HB / 16);
+  if (wave < YT) {
+    for (int k0 = 0; k0 < NT; k0 += 4) {
+      const int k = k0 + l4;
+      const double xre = su.Br[yti * 16 + l15][k];
+      const double qr = su.Ar[k][hB * HB + ytj * 16 + l15];
+      yr = Mfma<double>::mma(xre, qr, yr);
+      if constexpr (CPLX) {
+        const double xim = su.Bi[yti * 16 + l15][k];
+        const double qi = su.Ai[k][hB * HB + ytj * 16 + l15];
+        yr = Mfma<double>::mma(-xim, qi, yr);
+        yi = Mfma<double>::mma(xre, qi, yi);
+        yi = Mfma<double>::mma(xim, qr, yi);
+      }
+    }
+  }
+  __syncthreads();   // the update-shaped buffers are dead from here: the tile image overwrites them
+  if (wave < YT) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = yti * 16 + Mfma<double>::row(lane, r), col = ytj * 16 + l15;
+      st.Mr[row][HB + col] = yr[r];
+      st.Mr[HB + col][row] = yr[r];
+      if constexpr (CPLX) {
+        st.Mi[row][HB + col] = yi[r];
+        st.Mi[HB + col][row] = -yi[r];
+      }
+    }
+  }
+  for (int e = tid; e < HB * HB; e += 256) {
+    const int i = e / HB, j = e % HB;
+    const int64_t oa = ja + (int64_t)(hA * HB + i) * NT + hA * HB + j, ob = jb + (int64_t)(hB * HB + i) * NT + hB * HB + j;
+    st.Mr[i][j] = Dr[oa];
+    st.Mr[HB + i][HB + j] = Dr[ob];
+    if constexpr (CPLX) {
+      st.Mi[i][j] = Di[oa];
+      st.Mi[HB + i][HB + j] = Di[ob];
+    }
+  }
+  for (int e = tid; e < NT * NT; e += 256) {
+    st.Vr[e / NT][e % NT] = (e / NT == e % NT) ? 1.0 : 0.0;
+    if constexpr (CPLX) st.Vi[e / NT][e % NT] = 0.0;
+  }
+  __syncthreads();
+}
+
 template <int NT, bool CPLX>
 __global__ __launch_bounds__(256, 2) void jacobi_tile_evd_kernel(const double* Gr, const double* Gi, int ld, double* Jr, double* Ji,
                                                                  double* Dr, double* Di, double tol, const double* scal,
@@ -528,9 +659,9 @@ __global__ __launch_bounds__(256, 2) void jacobi_update_kernel(const double* Gr_
                                      ld);
 }
 
-// Fused launch of one round: the first S workgroups solve the diagonal tiles of round r+1 (already written by the
-// MODE 1 "head" launch of round r), all others run the bulk (MODE 2) of round r's update.  Low block ids are
-// dispatched first, so the latency-bound tile solves start at once and hide behind the MFMA-bound update tiles.
+// One round = ONE launch.  The first S workgroups assemble and sweep the diagonal tiles of round r+1 (from G, J, D of
+// round r: jacobi_assemble_next_diag), all others run the complete update of round r (MODE 0).  Low block ids are
+// dispatched first, so the latency-bound tile solves start at once and hide behind the HBM/MFMA-bound update tiles.
 template <int NT, bool CPLX>
 __global__ __launch_bounds__(256, 2) void jacobi_fused_round_kernel(const double* Gr_in, const double* Gi_in, double* Gr_out,
                                                                     double* Gi_out, const double* Zr_in, const double* Zi_in,
@@ -545,12 +676,14 @@ __global__ __launch_bounds__(256, 2) void jacobi_fused_round_kernel(const double
     JacUpdSmem<NT, CPLX> u;
     __device__ U() {}
   } sm;
-  if ((int)blockIdx.x < S)
-    jacobi_tile_evd_body<NT, CPLX>(sm.t, blockIdx.x, Gr_out, Gi_out, ld, Jr_next, Ji_next, Dr_next, Di_next, tol, scal, sweep_off,
-                                   max_sweeps, cross_only != 0);
-  else
-    jacobi_update_body<NT, CPLX, 2>(sm.u, (int)blockIdx.x - S, Gr_in, Gi_in, Gr_out, Gi_out, Zr_in, Zi_in, Zr_out, Zi_out, Jr, Ji,
+  if ((int)blockIdx.x < S) {
+    jacobi_assemble_next_diag<NT, CPLX>(sm.t, sm.u, blockIdx.x, S, Gr_in, Gi_in, ld, Jr, Ji, Dr, Di);
+    jacobi_tile_evd_body<NT, CPLX, true>(sm.t, blockIdx.x, nullptr, nullptr, ld, Jr_next, Ji_next, Dr_next, Di_next, tol, scal,
+                                         sweep_off, max_sweeps, cross_only != 0);
+  } else {
+    jacobi_update_body<NT, CPLX, 0>(sm.u, (int)blockIdx.x - S, Gr_in, Gi_in, Gr_out, Gi_out, Zr_in, Zi_in, Zr_out, Zi_out, Jr, Ji,
                                     Dr, Di, S, ld);
+  }
 }
 
 __global__ void jacobi_diag_kernel(const double* __restrict__ Gr, int npad, double* __restrict__ d) {
@@ -685,11 +818,9 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
         evd(st, cur, par, sweep, r);
         update(std::integral_constant<int, 0>{}, st, par, S + n_off + S * zchunks);
       } else {
-        // head of round r (diagonal tiles + the S tiles that form the next diagonal), then ONE launch with the
-        // diagonal-tile solves of round r+1 in front of the bulk of round r
-        update(std::integral_constant<int, 1>{}, st, par, 2 * S);
+        // ONE launch: tile solves of round r+1 (assembled from this round's G, J, D) + the whole update of round r
         const int next_slot = (r == rounds - 1) ? sweep + 1 : sweep;
-        hipLaunchKernelGGL((jacobi_fused_round_kernel<NT, CPLX>), dim3(S + n_off + S * zchunks), dim3(256), 0, st,
+        hipLaunchKernelGGL((jacobi_fused_round_kernel<NT, CPLX>), dim3(S + S + n_off + S * zchunks), dim3(256), 0, st,
                            ws.G[cur][0].get(), CPLX ? ws.G[cur][1].get() : nullptr, ws.G[cur ^ 1][0].get(),
                            CPLX ? ws.G[cur ^ 1][1].get() : nullptr, ws.Z[cur][0].get(), CPLX ? ws.Z[cur][1].get() : nullptr,
                            ws.Z[cur ^ 1][0].get(), CPLX ? ws.Z[cur ^ 1][1].get() : nullptr, ws.J[par][0].get(),
