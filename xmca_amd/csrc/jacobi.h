@@ -311,7 +311,7 @@ __device__ __forceinline__ void jacobi_update_body(JacUpdSmem<NT, CPLX>& sm, con
                                                    const double* __restrict__ Zi_in, double* __restrict__ Zr_out,
                                                    double* __restrict__ Zi_out, const double* __restrict__ Jr,
                                                    const double* __restrict__ Ji, const double* __restrict__ Dr,
-                                                   const double* __restrict__ Di, int S, int ld) {
+                                                   const double* __restrict__ Di, int S, int ld, const bool upper_store) {
   constexpr int LD = NT + 1;
   constexpr int HB = NT / 2;
   constexpr int TPD = NT / 16;          // MFMA tiles per dimension
@@ -362,10 +362,13 @@ __device__ __forceinline__ void jacobi_update_body(JacUpdSmem<NT, CPLX>& sm, con
 
   if (kind == 0) {
     // the diagonal tile was transformed by the tile solver itself (J_P^H G[P,P] J_P); move it to its destination blocks
+    // upper_store: nothing ever reads a half-block below the block diagonal again (tiles are taken from the upper
+    // triangle, diagonal tiles from D), so its off-diagonal quarter is written once, in whichever orientation is upper
     for (int e = tid; e < NT * NT; e += 256) {
       const int r = e / NT, c = e % NT;
-      const int dr = jacobi_dest_block(P, r / HB, S) * HB + r % HB;
-      const int dc = jacobi_dest_block(P, c / HB, S) * HB + c % HB;
+      const int br = jacobi_dest_block(P, r / HB, S), bc = jacobi_dest_block(P, c / HB, S);
+      if (upper_store && br > bc) continue;
+      const int dr = br * HB + r % HB, dc = bc * HB + c % HB;
       const int64_t o = (int64_t)dr * ld + dc;
       Gr_out[o] = Dr[(int64_t)P * NT * NT + e];
       if constexpr (CPLX) Gi_out[o] = Di[(int64_t)P * NT * NT + e];
@@ -498,16 +501,20 @@ __device__ __forceinline__ void jacobi_update_body(JacUpdSmem<NT, CPLX>& sm, con
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
       const int e = tid + 256 * i, r = e / NT, c = e % NT;
-      const int dr = jacobi_dest_block(P, r / HB, S) * HB + r % HB;
-      const int dc = jacobi_dest_block(Q, c / HB, S) * HB + c % HB;
-      JAC_STORE(&Gr_out[(int64_t)dr * ld + dc], Br[r][c]);
-      if constexpr (CPLX) JAC_STORE(&Gi_out[(int64_t)dr * ld + dc], Bi[r][c]);
+      const int br = jacobi_dest_block(P, r / HB, S), bc = jacobi_dest_block(Q, c / HB, S);
+      if (!upper_store || br < bc) {
+        const int dr = br * HB + r % HB, dc = bc * HB + c % HB;
+        JAC_STORE(&Gr_out[(int64_t)dr * ld + dc], Br[r][c]);
+        if constexpr (CPLX) JAC_STORE(&Gi_out[(int64_t)dr * ld + dc], Bi[r][c]);
+      }
       // mirrored element: this thread now plays (row' = c-index, col' = r-index) with r fastest
       const int r2 = e % NT, c2 = e / NT;
-      const int dr2 = jacobi_dest_block(P, r2 / HB, S) * HB + r2 % HB;
-      const int dc2 = jacobi_dest_block(Q, c2 / HB, S) * HB + c2 % HB;
-      JAC_STORE(&Gr_out[(int64_t)dc2 * ld + dr2], Br[r2][c2]);
-      if constexpr (CPLX) JAC_STORE(&Gi_out[(int64_t)dc2 * ld + dr2], -Bi[r2][c2]);
+      const int br2 = jacobi_dest_block(P, r2 / HB, S), bc2 = jacobi_dest_block(Q, c2 / HB, S);
+      if (!upper_store || br2 > bc2) {
+        const int dr2 = br2 * HB + r2 % HB, dc2 = bc2 * HB + c2 % HB;
+        JAC_STORE(&Gr_out[(int64_t)dc2 * ld + dr2], Br[r2][c2]);
+        if constexpr (CPLX) JAC_STORE(&Gi_out[(int64_t)dc2 * ld + dr2], -Bi[r2][c2]);
+      }
     }
   }
 }
@@ -656,7 +663,7 @@ __global__ __launch_bounds__(256, 2) void jacobi_update_kernel(const double* Gr_
                                                                const double* Dr, const double* Di, int S, int ld) {
   __shared__ JacUpdSmem<NT, CPLX> sm;
   jacobi_update_body<NT, CPLX, MODE>(sm, blockIdx.x, Gr_in, Gi_in, Gr_out, Gi_out, Zr_in, Zi_in, Zr_out, Zi_out, Jr, Ji, Dr, Di, S,
-                                     ld);
+                                     ld, false);
 }
 
 // One round = ONE launch.  The first S workgroups assemble and sweep the diagonal tiles of round r+1 (from G, J, D of
@@ -682,7 +689,7 @@ __global__ __launch_bounds__(256, 2) void jacobi_fused_round_kernel(const double
                                          sweep_off, max_sweeps, cross_only != 0);
   } else {
     jacobi_update_body<NT, CPLX, 0>(sm.u, (int)blockIdx.x - S, Gr_in, Gi_in, Gr_out, Gi_out, Zr_in, Zi_in, Zr_out, Zi_out, Jr, Ji,
-                                    Dr, Di, S, ld);
+                                    Dr, Di, S, ld, true);
   }
 }
 

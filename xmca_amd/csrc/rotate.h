@@ -685,6 +685,7 @@ __device__ void varimax_polar_step(double* __restrict__ sm, const double* __rest
     for (int e = tid; e < pp; e += 256) {
       const int j = e / p, k = e % p;
       double tr = 0.0, ti = 0.0;
+#pragma unroll 5
       for (int m = 0; m < p; ++m) {
         const double ar = Cr[m * p + j], br = Cr[m * p + k];
         tr += ar * br;
@@ -711,6 +712,7 @@ __device__ void varimax_polar_step(double* __restrict__ sm, const double* __rest
     for (int e = tid; e < pp; e += 256) {
       const int j = e / p, k = e % p;
       double yr = 0.0, yi = 0.0;
+#pragma unroll 5
       for (int m = 0; m < p; ++m) {
         const double xr = Cr[j * p + m], t_r = Tr[m * p + k];
         yr += xr * t_r;
@@ -748,6 +750,7 @@ __device__ void varimax_polar_step(double* __restrict__ sm, const double* __rest
   for (int e = tid; e < pp; e += 256) {
     const int j = e / p, k = e % p;
     double tr = 0.0, ti = 0.0;
+#pragma unroll 5
     for (int l = 0; l < p; ++l) {
       const double ar = Tr[j * p + l], rr = Xr[l * p + k];
       tr += ar * rr;
