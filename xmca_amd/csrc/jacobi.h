@@ -78,6 +78,35 @@ __global__ void jacobi_init_kernel(const double* __restrict__ Ar, const double* 
   }
 }
 
+#ifdef XMCA_JAC_PROF
+// phase stamps of the persistent update (profiling builds only): [workgroup][iteration][stamp]
+constexpr int JAC_PROF_IT = 12, JAC_PROF_ST = 10, JAC_PROF_WG = 512;
+__device__ long long jac_prof[JAC_PROF_WG * JAC_PROF_IT * JAC_PROF_ST];
+#define JAC_STAMP(k)                                                                                                  \
+  do {                                                                                                                \
+    if (tid == 0 && iter < JAC_PROF_IT && blockIdx.x < JAC_PROF_WG)                                                   \
+      jac_prof[((int)blockIdx.x * JAC_PROF_IT + iter) * JAC_PROF_ST + (k)] = (long long)__builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define JAC_STAMP(k) do { } while (0)
+#endif
+// 1/sqrt(x) and 1/x for normal positive x, full double precision: hardware seed, three Newton steps
+__device__ __forceinline__ double jac_rsqrt(const double x) {
+  double y = __builtin_amdgcn_rsq(x);
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    const double h = 0.5 * x * y;
+    y = fma(y, fma(-h, y, 0.5), y);
+  }
+  return y;
+}
+__device__ __forceinline__ double jac_rcp(const double x) {
+  double y = __builtin_amdgcn_rcp(x);
+#pragma unroll
+  for (int it = 0; it < 3; ++it) y = fma(y, fma(-x, y, 1.0), y);
+  return y;
+}
+
 // LDS images of the two kernel bodies (a fused launch runs both kinds of workgroups, so they share one union)
 template <int NT, bool CPLX>
 struct JacTileSmem {
@@ -180,6 +209,9 @@ __device__ __forceinline__ void jacobi_tile_evd_body(JacTileSmem<NT, CPLX>& sm, 
     if (tid == 0) flag = 0;
     __syncthreads();
     for (int step = 0; step < n_steps; ++step) {
+#ifdef XMCA_JAC_PROF
+      if (PRELOADED && tid == 0 && step >= 1 && step < JAC_PROF_IT) jac_prof[((int)blockIdx.x * JAC_PROF_IT + step) * JAC_PROF_ST + 2] = (long long)__builtin_readcyclecounter();
+#endif
       if (tid < H) {
         int p, q;
         pair_of(tid, step, p, q);
@@ -191,10 +223,13 @@ __device__ __forceinline__ void jacobi_tile_evd_body(JacTileSmem<NT, CPLX>& sm, 
         double c = 1.0, sr = 0.0, si = 0.0;
         if (g2 > abs_floor * abs_floor && g2 > tol * tol * fabs(app * aqq)) {
           // t = sign(d) 2|g| / (|d| + sqrt(d^2 + 4|g|^2)),  c = 1/sqrt(1+t^2),  s e^{i phi} = t c g/|g|
+          // (hardware rsq/rcp seeds + Newton steps: this scalar chain sits on the serial path of every rotation step,
+          //  and the IEEE sqrt/divide expansions are ~4x longer; c^2 + |s|^2 = 1 still holds to rounding)
           const double d = aqq - app;
-          const double inv = 1.0 / (fabs(d) + sqrt(d * d + 4.0 * g2));
+          const double x = d * d + 4.0 * g2;
+          const double inv = jac_rcp(fabs(d) + x * jac_rsqrt(x));
           const double w = (d >= 0.0 ? 2.0 : -2.0) * inv;       // t / |g|
-          c = 1.0 / sqrt(1.0 + w * w * g2);
+          c = jac_rsqrt(1.0 + w * w * g2);
           sr = w * c * gr;
           si = w * c * gi;
           flag = 1;
@@ -202,71 +237,110 @@ __device__ __forceinline__ void jacobi_tile_evd_body(JacTileSmem<NT, CPLX>& sm, 
         rc[tid] = c; rsr[tid] = sr; rsi[tid] = si;
       }
       __syncthreads();
+#ifdef XMCA_JAC_PROF
+      if (PRELOADED && tid == 0 && step >= 1 && step < JAC_PROF_IT) jac_prof[((int)blockIdx.x * JAC_PROF_IT + step) * JAC_PROF_ST + 3] = (long long)__builtin_readcyclecounter();
+#endif
       int p2, q2;
       pair_of(k2, step, p2, q2);
       const double c2 = rc[k2], s2r = rsr[k2], s2i = CPLX ? rsi[k2] : 0.0;
       const bool id2 = (c2 == 1.0 && s2r == 0.0 && s2i == 0.0);
-      // M <- J^H M J as (NT/2)^2 independent 2x2 blocks
+      // M <- J^H M J as (NT/2)^2 independent 2x2 blocks, V <- V J on this thread's rows.  Everything is read into
+      // registers first and written back at the end: the blocks of one thread never overlap, but the compiler cannot
+      // know that, and a read-compute-write loop per block costs one LDS round trip per block (5 in a row; 3.6k
+      // cycles per step measured) on what is the serial path of the solver.  An identity rotation (c = 1, s = 0)
+      // reproduces its operands exactly, so no block is skipped.
+      double mr[NBLK][4], mi[CPLX ? NBLK : 1][4];
+      double c1[NBLK], s1r[NBLK], s1i[NBLK];
+      int p1[NBLK], q1[NBLK];
+      double vr[NROW][2], vi[CPLX ? NROW : 1][2];
 #pragma unroll
       for (int b = 0; b < NBLK; ++b) {
         const int k1 = kb + KSTRIDE * b;
-        const double c1 = rc[k1], s1r = rsr[k1], s1i = CPLX ? rsi[k1] : 0.0;
-        if (id2 && c1 == 1.0 && s1r == 0.0 && s1i == 0.0) continue;
-        int p1, q1;
-        pair_of(k1, step, p1, q1);
-        const double b00r = Mr[p1][p2], b01r = Mr[p1][q2], b10r = Mr[q1][p2], b11r = Mr[q1][q2];
+        pair_of(k1, step, p1[b], q1[b]);
+        c1[b] = rc[k1]; s1r[b] = rsr[k1]; s1i[b] = CPLX ? rsi[k1] : 0.0;
+        mr[b][0] = Mr[p1[b]][p2]; mr[b][1] = Mr[p1[b]][q2]; mr[b][2] = Mr[q1[b]][p2]; mr[b][3] = Mr[q1[b]][q2];
+        if constexpr (CPLX) { mi[b][0] = Mi[p1[b]][p2]; mi[b][1] = Mi[p1[b]][q2]; mi[b][2] = Mi[q1[b]][p2]; mi[b][3] = Mi[q1[b]][q2]; }
+      }
+#pragma unroll
+      for (int r = 0; r < NROW; ++r) {
+        const int i = kb + KSTRIDE * r;
+        vr[r][0] = Vr[i][p2]; vr[r][1] = Vr[i][q2];
+        if constexpr (CPLX) { vi[r][0] = Vi[i][p2]; vi[r][1] = Vi[i][q2]; }
+      }
+#pragma unroll
+      for (int b = 0; b < NBLK; ++b) {
+        const int k1 = kb + KSTRIDE * b;
+        const double b00r = mr[b][0], b01r = mr[b][1], b10r = mr[b][2], b11r = mr[b][3];
+        const double cc = c1[b], sr = s1r[b], si = s1i[b];
         if constexpr (!CPLX) {
           // rows: x0 = c1 b0 - s1 b1 ; x1 = s1 b0 + c1 b1
-          const double x00 = c1 * b00r - s1r * b10r, x01 = c1 * b01r - s1r * b11r;
-          const double x10 = s1r * b00r + c1 * b10r, x11 = s1r * b01r + c1 * b11r;
+          const double x00 = cc * b00r - sr * b10r, x01 = cc * b01r - sr * b11r;
+          const double x10 = sr * b00r + cc * b10r, x11 = sr * b01r + cc * b11r;
           // cols: y_i0 = c2 x_i0 - s2 x_i1 ; y_i1 = s2 x_i0 + c2 x_i1
           double y00 = c2 * x00 - s2r * x01, y01 = s2r * x00 + c2 * x01;
           double y10 = c2 * x10 - s2r * x11, y11 = s2r * x10 + c2 * x11;
           if (k1 == k2) { y01 = 0.0; y10 = 0.0; }
-          Mr[p1][p2] = y00; Mr[p1][q2] = y01; Mr[q1][p2] = y10; Mr[q1][q2] = y11;
+          mr[b][0] = y00; mr[b][1] = y01; mr[b][2] = y10; mr[b][3] = y11;
         } else {
-          const double b00i = Mi[p1][p2], b01i = Mi[p1][q2], b10i = Mi[q1][p2], b11i = Mi[q1][q2];
+          const double b00i = mi[b][0], b01i = mi[b][1], b10i = mi[b][2], b11i = mi[b][3];
           // x0j = c1 b0j - sg1 b1j ; x1j = conj(sg1) b0j + c1 b1j        (sg = sr + i si)
-          const double x00r = c1 * b00r - (s1r * b10r - s1i * b10i), x00i = c1 * b00i - (s1r * b10i + s1i * b10r);
-          const double x01r = c1 * b01r - (s1r * b11r - s1i * b11i), x01i = c1 * b01i - (s1r * b11i + s1i * b11r);
-          const double x10r = (s1r * b00r + s1i * b00i) + c1 * b10r, x10i = (s1r * b00i - s1i * b00r) + c1 * b10i;
-          const double x11r = (s1r * b01r + s1i * b01i) + c1 * b11r, x11i = (s1r * b01i - s1i * b01r) + c1 * b11i;
+          const double x00r = cc * b00r - (sr * b10r - si * b10i), x00i = cc * b00i - (sr * b10i + si * b10r);
+          const double x01r = cc * b01r - (sr * b11r - si * b11i), x01i = cc * b01i - (sr * b11i + si * b11r);
+          const double x10r = (sr * b00r + si * b00i) + cc * b10r, x10i = (sr * b00i - si * b00r) + cc * b10i;
+          const double x11r = (sr * b01r + si * b01i) + cc * b11r, x11i = (sr * b01i - si * b01r) + cc * b11i;
           // yi0 = c2 xi0 - conj(sg2) xi1 ; yi1 = sg2 xi0 + c2 xi1
           double y00r = c2 * x00r - (s2r * x01r + s2i * x01i), y00i = c2 * x00i - (s2r * x01i - s2i * x01r);
           double y01r = (s2r * x00r - s2i * x00i) + c2 * x01r, y01i = (s2r * x00i + s2i * x00r) + c2 * x01i;
           double y10r = c2 * x10r - (s2r * x11r + s2i * x11i), y10i = c2 * x10i - (s2r * x11i - s2i * x11r);
           double y11r = (s2r * x10r - s2i * x10i) + c2 * x11r, y11i = (s2r * x10i + s2i * x10r) + c2 * x11i;
           if (k1 == k2) { y01r = y01i = y10r = y10i = 0.0; y00i = 0.0; y11i = 0.0; }
-          Mr[p1][p2] = y00r; Mr[p1][q2] = y01r; Mr[q1][p2] = y10r; Mr[q1][q2] = y11r;
-          Mi[p1][p2] = y00i; Mi[p1][q2] = y01i; Mi[q1][p2] = y10i; Mi[q1][q2] = y11i;
+          mr[b][0] = y00r; mr[b][1] = y01r; mr[b][2] = y10r; mr[b][3] = y11r;
+          mi[b][0] = y00i; mi[b][1] = y01i; mi[b][2] = y10i; mi[b][3] = y11i;
         }
       }
       // V <- V J   (columns p2, q2 of this thread's rows)
-      if (!id2) {
 #pragma unroll
-        for (int r = 0; r < NROW; ++r) {
-          const int i = kb + KSTRIDE * r;
-          const double vpr = Vr[i][p2], vqr = Vr[i][q2];
-          if constexpr (!CPLX) {
-            Vr[i][p2] = c2 * vpr - s2r * vqr;
-            Vr[i][q2] = s2r * vpr + c2 * vqr;
-          } else {
-            const double vpi = Vi[i][p2], vqi = Vi[i][q2];
-            // new_p = c vp - conj(sg) vq ; new_q = sg vp + c vq
-            Vr[i][p2] = c2 * vpr - (s2r * vqr + s2i * vqi);
-            Vi[i][p2] = c2 * vpi - (s2r * vqi - s2i * vqr);
-            Vr[i][q2] = (s2r * vpr - s2i * vpi) + c2 * vqr;
-            Vi[i][q2] = (s2r * vpi + s2i * vpr) + c2 * vqi;
-          }
+      for (int r = 0; r < NROW; ++r) {
+        const double vpr = vr[r][0], vqr = vr[r][1];
+        if constexpr (!CPLX) {
+          vr[r][0] = c2 * vpr - s2r * vqr;
+          vr[r][1] = s2r * vpr + c2 * vqr;
+        } else {
+          const double vpi = vi[r][0], vqi = vi[r][1];
+          // new_p = c vp - conj(sg) vq ; new_q = sg vp + c vq
+          vr[r][0] = c2 * vpr - (s2r * vqr + s2i * vqi);
+          vi[r][0] = c2 * vpi - (s2r * vqi - s2i * vqr);
+          vr[r][1] = (s2r * vpr - s2i * vpi) + c2 * vqr;
+          vi[r][1] = (s2r * vpi + s2i * vpr) + c2 * vqi;
         }
       }
+#pragma unroll
+      for (int b = 0; b < NBLK; ++b) {
+        Mr[p1[b]][p2] = mr[b][0]; Mr[p1[b]][q2] = mr[b][1]; Mr[q1[b]][p2] = mr[b][2]; Mr[q1[b]][q2] = mr[b][3];
+        if constexpr (CPLX) { Mi[p1[b]][p2] = mi[b][0]; Mi[p1[b]][q2] = mi[b][1]; Mi[q1[b]][p2] = mi[b][2]; Mi[q1[b]][q2] = mi[b][3]; }
+      }
+#pragma unroll
+      for (int r = 0; r < NROW; ++r) {
+        const int i = kb + KSTRIDE * r;
+        Vr[i][p2] = vr[r][0]; Vr[i][q2] = vr[r][1];
+        if constexpr (CPLX) { Vi[i][p2] = vi[r][0]; Vi[i][q2] = vi[r][1]; }
+      }
+#ifdef XMCA_JAC_PROF
+      if (PRELOADED && tid == 0 && step >= 1 && step < JAC_PROF_IT) jac_prof[((int)blockIdx.x * JAC_PROF_IT + step) * JAC_PROF_ST + 4] = (long long)__builtin_readcyclecounter();
+#endif
       __syncthreads();
+#ifdef XMCA_JAC_PROF
+      if (PRELOADED && tid == 0 && step >= 1 && step < JAC_PROF_IT) jac_prof[((int)blockIdx.x * JAC_PROF_IT + step) * JAC_PROF_ST + 5] = (long long)__builtin_readcyclecounter();
+#endif
     }
     const int f = flag;
     __syncthreads();
     if (!f) break;
   }
 
+#ifdef XMCA_JAC_PROF
+  if (PRELOADED && tid == 0) jac_prof[((int)blockIdx.x * JAC_PROF_IT) * JAC_PROF_ST + 6] = (long long)__builtin_readcyclecounter();
+#endif
   const int64_t jb = (int64_t)P * NT * NT;
   for (int e = tid; e < NT * NT; e += 256) {
     const int i = e / NT, j = e % NT;
@@ -541,19 +615,58 @@ __device__ __forceinline__ void jacobi_assemble_next_diag(JacTileSmem<NT, CPLX>&
   constexpr int XT = (HB / 16) * (NT / 16);     // MFMA tiles of X (HB x NT): 8 or 2
   constexpr int XPW = (XT + 3) / 4;             // per wave: 2 or 1
   constexpr int YT = (HB / 16) * (HB / 16);     // MFMA tiles of Yq (HB x HB): 4 or 1
+  constexpr int EPT = NT * NT / 256;            // elements per thread of a full tile
+  constexpr int EPH = EPT / 2;                  // ... of a half tile (NT x HB) / of two quarters
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
   int A, hA, B, hB;
   jacobi_next_diag_halves(Pn, S, A, hA, B, hB);
   const int64_t ja = (int64_t)A * NT * NT, jb = (int64_t)B * NT * NT;
   const int64_t tbase = (int64_t)A * NT * ld + (int64_t)B * NT;
-  for (int e = tid; e < NT * NT; e += 256) {
-    const int r = e / NT, c = e % NT;
-    su.Ar[r][c] = Jr[ja + e];
-    su.Br[r][c] = Gr_in[tbase + (int64_t)r * ld + c];
-    if constexpr (CPLX) {
-      su.Ai[r][c] = Ji[ja + e];
-      su.Bi[r][c] = Gi_in[tbase + (int64_t)r * ld + c];
-    }
+  // This chain (assemble -> sweep -> next round's assemble) is the serial path of the whole solver: every global
+  // operand is requested before the first one is used, so one memory latency is exposed instead of three.
+  double tr[EPT], ti[CPLX ? EPT : 1];           // T = G[A,B]
+  double jar[EPH], jai[CPLX ? EPH : 1];         // J_A[:, hA half]   (NT x HB)
+  double jbr[EPH], jbi[CPLX ? EPH : 1];         // J_B[:, hB half]
+  double dar[EPH / 2], dai[CPLX ? EPH / 2 : 1]; // D_A[hA, hA] quarter (HB x HB)
+  double dbr[EPH / 2], dbi[CPLX ? EPH / 2 : 1]; // D_B[hB, hB] quarter
+#pragma unroll
+  for (int i = 0; i < EPH; ++i) {
+    const int e = tid + 256 * i, r = e / HB, c = e % HB;
+    jar[i] = Jr[ja + (int64_t)r * NT + hA * HB + c];
+    if constexpr (CPLX) jai[i] = Ji[ja + (int64_t)r * NT + hA * HB + c];
+  }
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) {
+    const int e = tid + 256 * i, r = e / NT, c = e % NT;
+    tr[i] = Gr_in[tbase + (int64_t)r * ld + c];
+    if constexpr (CPLX) ti[i] = Gi_in[tbase + (int64_t)r * ld + c];
+  }
+#pragma unroll
+  for (int i = 0; i < EPH; ++i) {
+    const int e = tid + 256 * i, r = e / HB, c = e % HB;
+    jbr[i] = Jr[jb + (int64_t)r * NT + hB * HB + c];
+    if constexpr (CPLX) jbi[i] = Ji[jb + (int64_t)r * NT + hB * HB + c];
+  }
+#pragma unroll
+  for (int i = 0; i < EPH / 2; ++i) {
+    const int e = tid + 256 * i, r = e / HB, c = e % HB;
+    const int64_t oa = ja + (int64_t)(hA * HB + r) * NT + hA * HB + c, ob = jb + (int64_t)(hB * HB + r) * NT + hB * HB + c;
+    dar[i] = Dr[oa];
+    dbr[i] = Dr[ob];
+    if constexpr (CPLX) { dai[i] = Di[oa]; dbi[i] = Di[ob]; }
+  }
+  // A[:, 0..HB) <- J_A half, B <- T
+#pragma unroll
+  for (int i = 0; i < EPH; ++i) {
+    const int e = tid + 256 * i, r = e / HB, c = e % HB;
+    su.Ar[r][c] = jar[i];
+    if constexpr (CPLX) su.Ai[r][c] = jai[i];
+  }
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) {
+    const int e = tid + 256 * i, r = e / NT, c = e % NT;
+    su.Br[r][c] = tr[i];
+    if constexpr (CPLX) su.Bi[r][c] = ti[i];
   }
   __syncthreads();
   // X = J_A[:, hA]^H T      (HB x NT)
@@ -563,18 +676,19 @@ __device__ __forceinline__ void jacobi_assemble_next_diag(JacTileSmem<NT, CPLX>&
     const int t = wave * XPW + a;
     d4_t ar = {0, 0, 0, 0}, ai = {0, 0, 0, 0};
     if (t < XT) {
-      const int ti = t / (NT / 16), tj = t % (NT / 16);
+      const int tii = t / (NT / 16), tj = t % (NT / 16);
+#pragma unroll 4
       for (int k0 = 0; k0 < NT; k0 += 4) {
         const int k = k0 + l4;
-        const double jr = su.Ar[k][hA * HB + ti * 16 + l15];
-        const double tr = su.Br[k][tj * 16 + l15];
-        ar = Mfma<double>::mma(jr, tr, ar);
+        const double jr = su.Ar[k][tii * 16 + l15];
+        const double trr = su.Br[k][tj * 16 + l15];
+        ar = Mfma<double>::mma(jr, trr, ar);
         if constexpr (CPLX) {
-          const double ji = su.Ai[k][hA * HB + ti * 16 + l15];
+          const double ji = su.Ai[k][tii * 16 + l15];
           const double tim = su.Bi[k][tj * 16 + l15];
           ar = Mfma<double>::mma(ji, tim, ar);
           ai = Mfma<double>::mma(jr, tim, ai);
-          ai = Mfma<double>::mma(-ji, tr, ai);
+          ai = Mfma<double>::mma(-ji, trr, ai);
         }
       }
     }
@@ -586,32 +700,35 @@ __device__ __forceinline__ void jacobi_assemble_next_diag(JacTileSmem<NT, CPLX>&
   for (int a = 0; a < XPW; ++a) {
     const int t = wave * XPW + a;
     if (t < XT) {
-      const int ti = t / (NT / 16), tj = t % (NT / 16);
+      const int tii = t / (NT / 16), tj = t % (NT / 16);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = ti * 16 + Mfma<double>::row(lane, r), col = tj * 16 + l15;
+        const int row = tii * 16 + Mfma<double>::row(lane, r), col = tj * 16 + l15;
         su.Br[row][col] = xr[a][r];
         if constexpr (CPLX) su.Bi[row][col] = xi[a][r];
       }
     }
   }
-  for (int e = tid; e < NT * NT; e += 256) {
-    su.Ar[e / NT][e % NT] = Jr[jb + e];
-    if constexpr (CPLX) su.Ai[e / NT][e % NT] = Ji[jb + e];
+#pragma unroll
+  for (int i = 0; i < EPH; ++i) {
+    const int e = tid + 256 * i, r = e / HB, c = e % HB;
+    su.Ar[r][c] = jbr[i];
+    if constexpr (CPLX) su.Ai[r][c] = jbi[i];
   }
   __syncthreads();
   // Yq = X J_B[:, hB]      (HB x HB), one MFMA tile per wave
   d4_t yr = {0, 0, 0, 0}, yi = {0, 0, 0, 0};
   const int yti = wave / (HB / 16), ytj = wave % (HB / 16);
   if (wave < YT) {
+#pragma unroll 4
     for (int k0 = 0; k0 < NT; k0 += 4) {
       const int k = k0 + l4;
       const double xre = su.Br[yti * 16 + l15][k];
-      const double qr = su.Ar[k][hB * HB + ytj * 16 + l15];
+      const double qr = su.Ar[k][ytj * 16 + l15];
       yr = Mfma<double>::mma(xre, qr, yr);
       if constexpr (CPLX) {
         const double xim = su.Bi[yti * 16 + l15][k];
-        const double qi = su.Ai[k][hB * HB + ytj * 16 + l15];
+        const double qi = su.Ai[k][ytj * 16 + l15];
         yr = Mfma<double>::mma(-xim, qi, yr);
         yi = Mfma<double>::mma(xre, qi, yi);
         yi = Mfma<double>::mma(xim, qr, yi);
@@ -631,17 +748,19 @@ __device__ __forceinline__ void jacobi_assemble_next_diag(JacTileSmem<NT, CPLX>&
       }
     }
   }
-  for (int e = tid; e < HB * HB; e += 256) {
-    const int i = e / HB, j = e % HB;
-    const int64_t oa = ja + (int64_t)(hA * HB + i) * NT + hA * HB + j, ob = jb + (int64_t)(hB * HB + i) * NT + hB * HB + j;
-    st.Mr[i][j] = Dr[oa];
-    st.Mr[HB + i][HB + j] = Dr[ob];
+#pragma unroll
+  for (int i = 0; i < EPH / 2; ++i) {
+    const int e = tid + 256 * i, r = e / HB, c = e % HB;
+    st.Mr[r][c] = dar[i];
+    st.Mr[HB + r][HB + c] = dbr[i];
     if constexpr (CPLX) {
-      st.Mi[i][j] = Di[oa];
-      st.Mi[HB + i][HB + j] = Di[ob];
+      st.Mi[r][c] = dai[i];
+      st.Mi[HB + r][HB + c] = dbi[i];
     }
   }
-  for (int e = tid; e < NT * NT; e += 256) {
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) {
+    const int e = tid + 256 * i;
     st.Vr[e / NT][e % NT] = (e / NT == e % NT) ? 1.0 : 0.0;
     if constexpr (CPLX) st.Vi[e / NT][e % NT] = 0.0;
   }
@@ -666,9 +785,319 @@ __global__ __launch_bounds__(256, 2) void jacobi_update_kernel(const double* Gr_
                                      ld, false);
 }
 
-// One round = ONE launch.  The first S workgroups assemble and sweep the diagonal tiles of round r+1 (from G, J, D of
-// round r: jacobi_assemble_next_diag), all others run the complete update of round r (MODE 0).  Low block ids are
-// dispatched first, so the latency-bound tile solves start at once and hide behind the HBM/MFMA-bound update tiles.
+// ---- persistent, software-pipelined form of the MODE 0 update (fused round kernel) --------------------------------
+// Work items of a round, taken from an atomic counter (heaviest first):
+//   kind 1: G tile (P,Q), P < Q          J_P^H G[P,Q] J_Q      loads J_P, T, J_Q   - two tile products
+//   kind 2: eigenvector tiles (P, Q..Q+1) J_P^H Z[P,Q..]       loads J_P, T0, T1   - two tile products
+//   kind 0: diagonal tile P              move D_P to its destination quarters
+// While an item is in the MFMA / LDS / store phases the three tiles of the NEXT item are already in flight into
+// registers, so the HBM/L2 latency that the one-item-per-workgroup form exposes (waves idle 40 % of the time on
+// s_waitcnt, MI355X PMC) hides behind arithmetic.
+struct JacItem {
+  int kind, P, Q, nsub;
+};
+
+__device__ __forceinline__ JacItem jacobi_decode_item(int id, const int S, const int n_off, const int zch) {
+  JacItem it;
+  it.kind = -1; it.P = 0; it.Q = 0; it.nsub = 0;
+  if (id < 0) return it;
+  if (id < n_off) {
+    it.kind = 1;
+    int P = 0, rem = id;
+    while (rem >= S - 1 - P) { rem -= S - 1 - P; ++P; }
+    it.P = P; it.Q = P + 1 + rem;
+    return it;
+  }
+  id -= n_off;
+  if (id < S * zch) {
+    it.kind = 2;
+    it.P = id / zch;
+    it.Q = (id % zch) * 2;
+    it.nsub = min(2, S - it.Q);
+    return it;
+  }
+  id -= S * zch;
+  if (id < S) { it.kind = 0; it.P = id; }
+  return it;
+}
+
+typedef unsigned int jac_u32x2 __attribute__((ext_vector_type(2)));
+// buffer addressing: one SGPR descriptor per plane, a per-thread byte offset that is the same for every tile of an
+// item, and a wave-uniform (SGPR) byte offset per access - no 64-bit per-access address VGPRs, which is what lets three
+// prefetched tiles + the accumulators fit the 256 VGPRs of a 2-workgroup-per-CU kernel
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t jac_rsrc(const double* p, unsigned int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ double jac_ld(__amdgpu_buffer_rsrc_t rs, unsigned int voff, unsigned int soff) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
+}
+__device__ __forceinline__ void jac_st(double x, __amdgpu_buffer_rsrc_t rs, unsigned int voff, unsigned int soff) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(jac_u32x2, x), rs, voff, soff, 0);
+}
+
+template <int NT, bool CPLX>
+__device__ __forceinline__ void jacobi_persistent_update(JacUpdSmem<NT, CPLX>& sm, int* slot, unsigned int* __restrict__ counter,
+                                                         const double* __restrict__ Gr_in, const double* __restrict__ Gi_in,
+                                                         double* __restrict__ Gr_out, double* __restrict__ Gi_out,
+                                                         const double* __restrict__ Zr_in, const double* __restrict__ Zi_in,
+                                                         double* __restrict__ Zr_out, double* __restrict__ Zi_out,
+                                                         const double* __restrict__ Jr, const double* __restrict__ Ji,
+                                                         const double* __restrict__ Dr, const double* __restrict__ Di, const int S,
+                                                         const int ld, const int zch) {
+  constexpr int HB = NT / 2;
+  constexpr int TPD = NT / 16;
+  constexpr int NACC = TPD * TPD / 4;
+  constexpr int EPT = NT * NT / 256;   // tile elements per thread = passes over the tile
+  constexpr int RP = 256 / NT;         // tile rows covered by one pass
+  static_assert(HB % RP == 0, "a pass must not straddle the two half-blocks");
+  auto& Ar = sm.Ar;
+  auto& Br = sm.Br;
+  auto& Ai = sm.Ai;
+  auto& Bi = sm.Bi;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+  const int row0 = tid / NT, col = tid % NT;
+  const int n_off = S * (S - 1) / 2;
+
+  const unsigned int plane_bytes = (unsigned int)((size_t)ld * ld * sizeof(double));
+  const unsigned int j_bytes = (unsigned int)((size_t)S * NT * NT * sizeof(double));
+  const __amdgpu_buffer_rsrc_t rGr = jac_rsrc(Gr_in, plane_bytes), rGi = jac_rsrc(Gi_in, plane_bytes);
+  const __amdgpu_buffer_rsrc_t rZr = jac_rsrc(Zr_in, plane_bytes), rZi = jac_rsrc(Zi_in, plane_bytes);
+  const __amdgpu_buffer_rsrc_t oGr = jac_rsrc(Gr_out, plane_bytes), oGi = jac_rsrc(Gi_out, plane_bytes);
+  const __amdgpu_buffer_rsrc_t oZr = jac_rsrc(Zr_out, plane_bytes), oZi = jac_rsrc(Zi_out, plane_bytes);
+  const __amdgpu_buffer_rsrc_t rJr = jac_rsrc(Jr, j_bytes), rJi = jac_rsrc(Ji, j_bytes);
+  const __amdgpu_buffer_rsrc_t rDr = jac_rsrc(Dr, j_bytes), rDi = jac_rsrc(Di, j_bytes);
+  const unsigned int voff_T = (unsigned int)(row0 * ld + col) * 8u;   // element (row0, col) of a tile inside a plane
+  const unsigned int voff_J = (unsigned int)tid * 8u;                 // the same element of a packed NT x NT tile
+
+  struct Tile {
+    double r[EPT];
+    double i[CPLX ? EPT : 1];
+  };
+  Tile tP, tT, tQ;
+  // tile whose (0,0) element is at element offset `base`; consecutive passes are `pass` elements apart (both uniform)
+  auto fetch = [&](Tile& t, const __amdgpu_buffer_rsrc_t rr, const __amdgpu_buffer_rsrc_t ri, const unsigned int voff,
+                   const unsigned int base, const unsigned int pass) {
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const unsigned int soff = (base + (unsigned int)i * pass) * 8u;
+      t.r[i] = jac_ld(rr, voff, soff);
+      if constexpr (CPLX) t.i[i] = jac_ld(ri, voff, soff);
+    }
+  };
+  auto to_A = [&](const Tile& t) {
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      Ar[row0 + RP * i][col] = t.r[i];
+      if constexpr (CPLX) Ai[row0 + RP * i][col] = t.i[i];
+    }
+  };
+  auto to_B = [&](const Tile& t) {
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      Br[row0 + RP * i][col] = t.r[i];
+      if constexpr (CPLX) Bi[row0 + RP * i][col] = t.i[i];
+    }
+  };
+  auto issue_PT = [&](const JacItem& it) {
+    if (it.kind <= 0) return;
+    fetch(tP, rJr, rJi, voff_J, (unsigned int)(it.P * NT * NT), 256u);
+    const unsigned int tb = (unsigned int)(it.P * NT * ld + it.Q * NT);
+    if (it.kind == 1) fetch(tT, rGr, rGi, voff_T, tb, (unsigned int)(RP * ld));
+    else fetch(tT, rZr, rZi, voff_T, tb, (unsigned int)(RP * ld));
+  };
+  auto issue_Q = [&](const JacItem& it) {
+    if (it.kind == 1) fetch(tQ, rJr, rJi, voff_J, (unsigned int)(it.Q * NT * NT), 256u);
+    else if (it.kind == 2 && it.nsub == 2)
+      fetch(tQ, rZr, rZi, voff_T, (unsigned int)(it.P * NT * ld + (it.Q + 1) * NT), (unsigned int)(RP * ld));
+  };
+  // B <- A^H B   (A = J_P, B = tile), through registers
+  auto mul_AhB = [&]() {
+    d4_t xr[NACC], xi[CPLX ? NACC : 1];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) {
+      const int t = wave * NACC + a, ti = t / TPD, tj = t % TPD;
+      d4_t ar = {0, 0, 0, 0}, ai = {0, 0, 0, 0};
+#pragma unroll 4
+      for (int k0 = 0; k0 < NT; k0 += 4) {
+        const int k = k0 + l4;
+        const double jr = Ar[k][ti * 16 + l15];
+        const double tr = Br[k][tj * 16 + l15];
+        ar = Mfma<double>::mma(jr, tr, ar);
+        if constexpr (CPLX) {
+          const double ji = Ai[k][ti * 16 + l15];
+          const double tim = Bi[k][tj * 16 + l15];
+          ar = Mfma<double>::mma(ji, tim, ar);
+          ai = Mfma<double>::mma(jr, tim, ai);
+          ai = Mfma<double>::mma(-ji, tr, ai);
+        }
+      }
+      xr[a] = ar;
+      if constexpr (CPLX) xi[a] = ai;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) {
+      const int t = wave * NACC + a, ti = t / TPD, tj = t % TPD;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = ti * 16 + Mfma<double>::row(lane, r), cc = tj * 16 + l15;
+        Br[row][cc] = xr[a][r];
+        if constexpr (CPLX) Bi[row][cc] = xi[a][r];
+      }
+    }
+  };
+  // B <- B A   (B = X, A = J_Q)
+  auto mul_BA = [&]() {
+    d4_t yr[NACC], yi[CPLX ? NACC : 1];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) {
+      const int t = wave * NACC + a, ti = t / TPD, tj = t % TPD;
+      d4_t ar = {0, 0, 0, 0}, ai = {0, 0, 0, 0};
+#pragma unroll 4
+      for (int k0 = 0; k0 < NT; k0 += 4) {
+        const int k = k0 + l4;
+        const double xre = Br[ti * 16 + l15][k];
+        const double qr = Ar[k][tj * 16 + l15];
+        ar = Mfma<double>::mma(xre, qr, ar);
+        if constexpr (CPLX) {
+          const double xim = Bi[ti * 16 + l15][k];
+          const double qi = Ai[k][tj * 16 + l15];
+          ar = Mfma<double>::mma(-xim, qi, ar);
+          ai = Mfma<double>::mma(xre, qi, ai);
+          ai = Mfma<double>::mma(xim, qr, ai);
+        }
+      }
+      yr[a] = ar;
+      if constexpr (CPLX) yi[a] = ai;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) {
+      const int t = wave * NACC + a, ti = t / TPD, tj = t % TPD;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = ti * 16 + Mfma<double>::row(lane, r), cc = tj * 16 + l15;
+        Br[row][cc] = yr[a][r];
+        if constexpr (CPLX) Bi[row][cc] = yi[a][r];
+      }
+    }
+  };
+  // rows of pass i belong to half (RP*i)/HB of the tile; inside the destination half-block they start at (RP*i)%HB
+  auto store_z = [&](const int P, const int Qc) {
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const int drow = jacobi_dest_block(P, (RP * i) / HB, S) * HB + (RP * i) % HB;
+      const unsigned int soff = (unsigned int)(drow * ld + Qc * NT) * 8u;
+      jac_st(Br[row0 + RP * i][col], oZr, voff_T, soff);
+      if constexpr (CPLX) jac_st(Bi[row0 + RP * i][col], oZi, voff_T, soff);
+    }
+  };
+
+  // slot[2], slot[3]: the first two item ids; slot[0], slot[1]: alternate per iteration, so that the single barrier at
+  // the bottom of the loop is enough (a slot is rewritten two iterations after it was read)
+  unsigned int pending = 0;
+  if (tid == 0) {
+    slot[2] = (int)atomicAdd(counter, 1u);
+    slot[3] = (int)atomicAdd(counter, 1u);
+  }
+  __syncthreads();
+  JacItem cur = jacobi_decode_item(__builtin_amdgcn_readfirstlane(slot[2]), S, n_off, zch);
+  int nxt_id = __builtin_amdgcn_readfirstlane(slot[3]);
+  issue_PT(cur);
+  issue_Q(cur);
+  for (int iter = 0; cur.kind >= 0; ++iter) {
+    JAC_STAMP(0);
+#ifdef XMCA_JAC_PROF
+    if (tid == 0 && iter < JAC_PROF_IT && blockIdx.x < JAC_PROF_WG) jac_prof[((int)blockIdx.x * JAC_PROF_IT + iter) * JAC_PROF_ST + 9] = cur.kind;
+#endif
+    if (tid == 0) pending = atomicAdd(counter, 1u);    // the item after next; consumed at the bottom of this iteration
+    const JacItem nxt = jacobi_decode_item(nxt_id, S, n_off, zch);
+    if (cur.kind == 0) {
+      // the diagonal tile was transformed by the tile solver itself (D_P = J_P^H G[P,P] J_P): move it to its destination
+      // quarters.  Nothing reads a half-block below the block diagonal again (tiles are taken from the upper triangle,
+      // diagonal tiles from D), so only the upper ones are written.
+      issue_PT(nxt);
+      issue_Q(nxt);
+      const int P = cur.P;
+      const int bc = jacobi_dest_block(P, col / HB, S);
+      const unsigned int voff = (unsigned int)(row0 * ld + bc * HB + col % HB) * 8u;
+#pragma unroll
+      for (int i = 0; i < EPT; ++i) {
+        const int br = jacobi_dest_block(P, (RP * i) / HB, S);
+        const unsigned int src = (unsigned int)(P * NT * NT + 256 * i) * 8u;
+        const unsigned int soff = (unsigned int)((br * HB + (RP * i) % HB) * ld) * 8u;
+        if (br <= bc) {
+          jac_st(jac_ld(rDr, voff_J, src), oGr, voff, soff);
+          if constexpr (CPLX) jac_st(jac_ld(rDi, voff_J, src), oGi, voff, soff);
+        }
+      }
+    } else {
+      to_A(tP);
+      to_B(tT);
+      JAC_STAMP(1);
+      __syncthreads();
+      JAC_STAMP(2);
+      issue_PT(nxt);
+      mul_AhB();          // B = X = J_P^H T  (contains the barrier between reading and overwriting B)
+      JAC_STAMP(3);
+      if (cur.kind == 1) {
+        to_A(tQ);         // J_P is dead: every wave passed the barrier inside mul_AhB
+        __syncthreads();
+        JAC_STAMP(4);
+        issue_Q(nxt);
+        mul_BA();         // B = Y = X J_Q
+        __syncthreads();
+        JAC_STAMP(5);
+        const int P = cur.P, Q = cur.Q;
+        // each quarter goes out once, in the orientation that lies above the block diagonal of the next round:
+        // as it is (element (r, c) of Y), or conjugate-transposed (this thread then plays row' = c-index, col' = r-index)
+        const int bq = jacobi_dest_block(Q, col / HB, S), bp = jacobi_dest_block(P, col / HB, S);
+        const unsigned int voff_n = (unsigned int)(row0 * ld + bq * HB + col % HB) * 8u;
+        const unsigned int voff_m = (unsigned int)(row0 * ld + bp * HB + col % HB) * 8u;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+          const int h = (RP * i) / HB, rin = (RP * i) % HB;
+          const int br = jacobi_dest_block(P, h, S);
+          if (br < bq) {
+            const unsigned int soff = (unsigned int)((br * HB + rin) * ld) * 8u;
+            jac_st(Br[row0 + RP * i][col], oGr, voff_n, soff);
+            if constexpr (CPLX) jac_st(Bi[row0 + RP * i][col], oGi, voff_n, soff);
+          }
+          const int bc2 = jacobi_dest_block(Q, h, S);
+          if (bp > bc2) {
+            const unsigned int soff = (unsigned int)((bc2 * HB + rin) * ld) * 8u;
+            jac_st(Br[col][row0 + RP * i], oGr, voff_m, soff);
+            if constexpr (CPLX) jac_st(-Bi[col][row0 + RP * i], oGi, voff_m, soff);
+          }
+        }
+      } else {
+        __syncthreads();
+        store_z(cur.P, cur.Q);
+        if (cur.nsub == 2) {
+          __syncthreads();
+          to_B(tQ);
+          __syncthreads();
+          issue_Q(nxt);
+          mul_AhB();
+          __syncthreads();
+          store_z(cur.P, cur.Q + 1);
+        } else {
+          issue_Q(nxt);
+        }
+      }
+    }
+    JAC_STAMP(6);
+    if (tid == 0) slot[iter & 1] = (int)pending;
+    __syncthreads();       // the LDS tiles are free again and the slot is visible
+    JAC_STAMP(7);
+    cur = nxt;
+    nxt_id = __builtin_amdgcn_readfirstlane(slot[iter & 1]);
+  }
+}
+
+// One round = ONE launch of at most two workgroups per CU.  The first S workgroups assemble and sweep the diagonal
+// tiles of round r+1 (from G, J, D of round r: jacobi_assemble_next_diag); every workgroup (those S too, once they
+// are done) then pulls update items of round r from the work counter until none is left.
 template <int NT, bool CPLX>
 __global__ __launch_bounds__(256, 2) void jacobi_fused_round_kernel(const double* Gr_in, const double* Gi_in, double* Gr_out,
                                                                     double* Gi_out, const double* Zr_in, const double* Zi_in,
@@ -677,20 +1106,51 @@ __global__ __launch_bounds__(256, 2) void jacobi_fused_round_kernel(const double
                                                                     double* Jr_next, double* Ji_next, double* Dr_next,
                                                                     double* Di_next, double tol, const double* scal,
                                                                     unsigned long long* sweep_off, int max_sweeps, int cross_only,
-                                                                    int S, int ld) {
+                                                                    int S, int ld, unsigned int* work_counter, int zch,
+                                                                    unsigned int* cu_table, unsigned int tag) {
   __shared__ union U {
     JacTileSmem<NT, CPLX> t;
     JacUpdSmem<NT, CPLX> u;
     __device__ U() {}
   } sm;
+  __shared__ int slot[4];
+#ifdef XMCA_JAC_PROF
+  if (threadIdx.x == 0 && blockIdx.x < JAC_PROF_WG) jac_prof[(int)blockIdx.x * JAC_PROF_IT * JAC_PROF_ST + 8] = (long long)__builtin_readcyclecounter();
+#endif
+  // The tile solves are the serial chain of the whole eigensolver and they are VALU/LDS-latency bound; a co-resident
+  // update workgroup (back-to-back f64 MFMA on the same SIMDs) slows their rotation steps 2.3x (s_memtime stamps on
+  // MI355X).  So a solver workgroup marks its CU, and an update workgroup that finds itself on a marked CU leaves
+  // before it claims any work (the counter hands its share to the others).  Placement is only read, never assumed:
+  // if the update workgroup happens to arrive first, both simply share the CU as before.
+  if (cu_table) {
+    const unsigned int key = (__builtin_amdgcn_s_getreg(6164 /* XCC_ID[3:0] */) << 8) | __builtin_amdgcn_s_getreg(14852 /* HW_ID[15:8]: SE, SH, CU */);
+    if ((int)blockIdx.x < S) {
+      if (threadIdx.x == 0) atomicMax(cu_table + key, 2u * tag + 1u);
+    } else {
+      if (threadIdx.x == 0) slot[0] = atomicMax(cu_table + key, 2u * tag) == 2u * tag + 1u;
+      __syncthreads();
+      const int leave = slot[0];
+      __syncthreads();
+      if (leave) return;
+    }
+  }
   if ((int)blockIdx.x < S) {
     jacobi_assemble_next_diag<NT, CPLX>(sm.t, sm.u, blockIdx.x, S, Gr_in, Gi_in, ld, Jr, Ji, Dr, Di);
+#ifdef XMCA_JAC_PROF
+    if (threadIdx.x == 0) jac_prof[(int)blockIdx.x * JAC_PROF_IT * JAC_PROF_ST + 0] = (long long)__builtin_readcyclecounter();
+#endif
     jacobi_tile_evd_body<NT, CPLX, true>(sm.t, blockIdx.x, nullptr, nullptr, ld, Jr_next, Ji_next, Dr_next, Di_next, tol, scal,
                                          sweep_off, max_sweeps, cross_only != 0);
-  } else {
-    jacobi_update_body<NT, CPLX, 0>(sm.u, (int)blockIdx.x - S, Gr_in, Gi_in, Gr_out, Gi_out, Zr_in, Zi_in, Zr_out, Zi_out, Jr, Ji,
-                                    Dr, Di, S, ld, true);
+    __syncthreads();     // the tile image is dead; this workgroup now helps with what is left of the update
+#ifdef XMCA_JAC_PROF
+    if (threadIdx.x == 0) jac_prof[(int)blockIdx.x * JAC_PROF_IT * JAC_PROF_ST + 1] = (long long)__builtin_readcyclecounter();
+#endif
   }
+#ifdef XMCA_JAC_PROF_NOUPD
+  return;
+#endif
+  jacobi_persistent_update<NT, CPLX>(sm.u, slot, work_counter, Gr_in, Gi_in, Gr_out, Gi_out, Zr_in, Zi_in, Zr_out, Zi_out, Jr, Ji, Dr,
+                                     Di, S, ld, zch);
 }
 
 __global__ void jacobi_diag_kernel(const double* __restrict__ Gr, int npad, double* __restrict__ d) {
@@ -717,6 +1177,8 @@ struct EvdWorkspace {
   DevBuf<double> diag, scal;
   DevBuf<unsigned long long> off;   // one accumulator per sweep (ring)
   DevBuf<int> perm;
+  DevBuf<unsigned int> work;        // one work counter per round (fused round kernel)
+  DevBuf<unsigned int> cu_table;    // per-CU marks of the solver workgroups (fused round kernel)
   hipStream_t aux = nullptr;        // second stream: diagonal-tile solves of the NEXT round
   hipEvent_t ev_head[4] = {nullptr, nullptr, nullptr, nullptr}, ev_evd[4] = {nullptr, nullptr, nullptr, nullptr};
   ~EvdWorkspace() {
@@ -814,6 +1276,24 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
                        ws.D[par][0].get(), CPLX ? ws.D[par][1].get() : nullptr, S, npad);
   };
 
+  // fused rounds: persistent workgroups (two per CU) pull items from one counter per round
+  const int zch2 = want_z ? (S + 1) / 2 : 0;
+  const int fused_items = n_off + S * zch2 + S;
+  static const int resident_wgs = [] {
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return 2 * cus;
+  }();
+  const int fused_grid = std::max(S, std::min(resident_wgs, S + fused_items));
+  static const bool exclusive_on = [] { const char* e = std::getenv("XMCA_JACOBI_EXCL"); return !(e && e[0] == '0'); }();
+  if (lookahead) {
+    ws.cu_table.ensure(4096);
+    XMCA_HIP(hipMemsetAsync(ws.cu_table.get(), 0, sizeof(unsigned int) * 4096, st));
+    ws.work.ensure((size_t)max_sweeps * rounds);
+    XMCA_HIP(hipMemsetAsync(ws.work.get(), 0, sizeof(unsigned int) * (size_t)max_sweeps * rounds, st));
+  }
+
   int sweeps = 0;
   double off = 0.0;
   int64_t round_no = 0;
@@ -827,14 +1307,15 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
       } else {
         // ONE launch: tile solves of round r+1 (assembled from this round's G, J, D) + the whole update of round r
         const int next_slot = (r == rounds - 1) ? sweep + 1 : sweep;
-        hipLaunchKernelGGL((jacobi_fused_round_kernel<NT, CPLX>), dim3(S + S + n_off + S * zchunks), dim3(256), 0, st,
+        hipLaunchKernelGGL((jacobi_fused_round_kernel<NT, CPLX>), dim3(fused_grid), dim3(256), 0, st,
                            ws.G[cur][0].get(), CPLX ? ws.G[cur][1].get() : nullptr, ws.G[cur ^ 1][0].get(),
                            CPLX ? ws.G[cur ^ 1][1].get() : nullptr, ws.Z[cur][0].get(), CPLX ? ws.Z[cur][1].get() : nullptr,
                            ws.Z[cur ^ 1][0].get(), CPLX ? ws.Z[cur ^ 1][1].get() : nullptr, ws.J[par][0].get(),
                            CPLX ? ws.J[par][1].get() : nullptr, ws.D[par][0].get(), CPLX ? ws.D[par][1].get() : nullptr,
                            ws.J[par ^ 1][0].get(), CPLX ? ws.J[par ^ 1][1].get() : nullptr, ws.D[par ^ 1][0].get(),
                            CPLX ? ws.D[par ^ 1][1].get() : nullptr, tile_tol, ws.scal.get(), ws.off.get() + next_slot,
-                           inner_cap, is_cross((r + 1) % rounds) ? 1 : 0, S, npad);
+                           inner_cap, is_cross((r + 1) % rounds) ? 1 : 0, S, npad, ws.work.get() + round_no, zch2,
+                           exclusive_on ? ws.cu_table.get() : nullptr, (unsigned int)(round_no + 1));
       }
       cur ^= 1;
     }
@@ -849,6 +1330,21 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
     if (S == 1 || !(off >= tol) || !std::isfinite(off)) break;
   }
   XMCA_CHECK(std::isfinite(off), XMCA_ERR_NUMERIC, "SVD failed. NaN entries may be the problem.");
+#ifdef XMCA_JAC_PROF
+  if (lookahead) {   // stamps of the last round
+    std::vector<long long> h((size_t)JAC_PROF_WG * JAC_PROF_IT * JAC_PROF_ST);
+    XMCA_HIP(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(jac_prof), h.size() * sizeof(long long)));
+    if (FILE* f = std::fopen("gpurun_out/jac_prof.txt", "w")) {
+      for (int w = 0; w < JAC_PROF_WG; ++w)
+        for (int it = 0; it < JAC_PROF_IT; ++it) {
+          std::fprintf(f, "%d %d", w, it);
+          for (int k = 0; k < JAC_PROF_ST; ++k) std::fprintf(f, " %lld", h[((size_t)w * JAC_PROF_IT + it) * JAC_PROF_ST + k]);
+          std::fprintf(f, "\n");
+        }
+      std::fclose(f);
+    }
+  }
+#endif
 
   // eigenvalues = diagonal; sort descending on the host, drop the padding (= the most negative entries)
   hipLaunchKernelGGL(jacobi_diag_kernel, dim3(ceil_div(npad, 256)), dim3(256), 0, st, ws.G[cur][0].get(), npad, ws.diag.get());
