@@ -72,3 +72,32 @@ def test_zero_row_is_linalg_error(hip):
     A[7] = 0.0           # Kaiser normalisation divides by the row norm -> NaN, as in the reference
     with pytest.raises(np.linalg.LinAlgError):
         hip.rotate_loadings(A, n_left=A.shape[0])
+
+
+def _wide_loadings(n, p, cplx, seed):
+    rng = np.random.default_rng(seed)
+    L = 0.15 * rng.standard_normal((n, p))
+    w = n // p
+    for j in range(p):
+        L[j * w:(j + 1) * w, j] += np.hanning(w) * (3.0 - 0.05 * j)
+    if cplx:
+        L = L * np.exp(1j * rng.uniform(0, 2 * np.pi, (n, 1)) * 0.3) + 0.05j * rng.standard_normal((n, p))
+        M = rng.standard_normal((p, p)) + 1j * rng.standard_normal((p, p))
+    else:
+        M = rng.standard_normal((p, p))
+    Q, _ = np.linalg.qr(M)
+    return L @ Q
+
+
+@pytest.mark.parametrize("n,p,cplx,seed", [(900, 17, False, 55), (600, 20, False, 51), (480, 24, True, 52),
+                                           (640, 32, True, 54), (800, 40, False, 53), (20000, 12, True, 56)])
+def test_varimax_many_modes_matches_oracle(hip, n, p, cplx, seed):
+    """More than 16 rotated modes take the multi-tile MFMA accumulation and the LDS Newton-Schulz path, many grid
+    points take several tiles per workgroup: same R, B and iteration count as the numpy restatement of rotation.py."""
+    from oracle import ref_numpy as O
+    A = _wide_loadings(n, p, cplx, seed)
+    B_ref, R_ref, n_iter = O.varimax(A)
+    out = hip.rotate_loadings(A, n_left=n, varimax_only=True, want_B=True)
+    assert out["n_iter"] == n_iter
+    assert _rel(out["R"], R_ref) < TOL
+    assert _rel(out["B"], B_ref) < TOL

@@ -186,7 +186,7 @@ __device__ __forceinline__ void jacobi_tile_evd_body(JacTileSmem<NT, CPLX>& sm, 
   constexpr int KSTRIDE = 256 / H;            // 8 (NT = 64) or 16 (NT = 32)
   constexpr int NBLK = (H * H) / 256;         // 2x2 blocks per thread: 4 or 1
   constexpr int NROW = NT / KSTRIDE;          // rows of V per thread: 8 or 2
-  const int k2 = tid % H, kb = tid / H;
+  const int k2 = tid % H, kb = tid / H, lane = tid & 63;
   // full mode: round-robin tournament over all NT indices (NT-1 steps).  cross mode: only the pairs (p, q) with p in
   // the first and q in the second half-block (NT/2 steps of cyclic shifts): the pairs inside a half-block have been
   // rotated when that half-block was last swept in full mode and need it only once per outer sweep.
@@ -205,6 +205,13 @@ __device__ __forceinline__ void jacobi_tile_evd_body(JacTileSmem<NT, CPLX>& sm, 
   };
   const int n_steps = cross_only ? H : NT - 1;
   __builtin_amdgcn_s_setprio(3);   // latency-bound: when sharing a CU with MFMA-bound update workgroups, issue first
+  // One barrier per step.  Every wave computes all H rotations itself (lane l holds the rotation of pair l % H, which
+  // is also this thread's column pair k2), so there is no "one wave computes, everybody waits" phase; the rotations of
+  // the row pairs k1 come from the lanes that hold them.  The V update of a step does not feed the next rotation
+  // angles, so it runs one step late, next to the (latency-bound, scalar) angle computation of the following step.
+  const double floor2 = abs_floor * abs_floor, tol2 = tol * tol;
+  double cv = 1.0, svr = 0.0, svi = 0.0;   // rotation of the pending V update (identity: nothing pending)
+  int pv = 0, qv = 1;
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
     if (tid == 0) flag = 0;
     __syncthreads();
@@ -212,66 +219,76 @@ __device__ __forceinline__ void jacobi_tile_evd_body(JacTileSmem<NT, CPLX>& sm, 
 #ifdef XMCA_JAC_PROF
       if (PRELOADED && tid == 0 && step >= 1 && step < JAC_PROF_IT) jac_prof[((int)blockIdx.x * JAC_PROF_IT + step) * JAC_PROF_ST + 2] = (long long)__builtin_readcyclecounter();
 #endif
-      if (tid < H) {
-        int p, q;
-        pair_of(tid, step, p, q);
-        const double app = Mr[p][p], aqq = Mr[q][q];
-        const double gr = Mr[p][q];
+      int p2, q2;
+      pair_of(k2, step, p2, q2);
+      double c2, s2r, s2i;
+      {
+        const double app = Mr[p2][p2], aqq = Mr[q2][q2];
+        const double gr = Mr[p2][q2];
         double gi = 0.0;
-        if constexpr (CPLX) gi = Mi[p][q];
+        if constexpr (CPLX) gi = Mi[p2][q2];
         const double g2 = gr * gr + gi * gi;
-        double c = 1.0, sr = 0.0, si = 0.0;
-        if (g2 > abs_floor * abs_floor && g2 > tol * tol * fabs(app * aqq)) {
-          // t = sign(d) 2|g| / (|d| + sqrt(d^2 + 4|g|^2)),  c = 1/sqrt(1+t^2),  s e^{i phi} = t c g/|g|
-          // (hardware rsq/rcp seeds + Newton steps: this scalar chain sits on the serial path of every rotation step,
-          //  and the IEEE sqrt/divide expansions are ~4x longer; c^2 + |s|^2 = 1 still holds to rounding)
-          const double d = aqq - app;
-          const double x = d * d + 4.0 * g2;
-          const double inv = jac_rcp(fabs(d) + x * jac_rsqrt(x));
-          const double w = (d >= 0.0 ? 2.0 : -2.0) * inv;       // t / |g|
-          c = jac_rsqrt(1.0 + w * w * g2);
-          sr = w * c * gr;
-          si = w * c * gi;
-          flag = 1;
-        }
-        rc[tid] = c; rsr[tid] = sr; rsi[tid] = si;
+        const bool rot = g2 > floor2 && g2 > tol2 * fabs(app * aqq);
+        // t = sign(d) 2|g| / (|d| + sqrt(d^2 + 4|g|^2)),  c = 1/sqrt(1+t^2),  s e^{i phi} = t c g/|g|
+        // (hardware rsq/rcp seeds + Newton steps; c^2 + |s|^2 = 1 holds to rounding)
+        const double d = aqq - app;
+        const double x = rot ? d * d + 4.0 * g2 : 1.0;
+        const double inv = jac_rcp(fabs(d) + x * jac_rsqrt(x));
+        const double w = (d >= 0.0 ? 2.0 : -2.0) * inv;       // t / |g|
+        const double c = jac_rsqrt(1.0 + (rot ? w * w * g2 : 0.0));
+        c2 = rot ? c : 1.0;
+        s2r = rot ? w * c * gr : 0.0;
+        s2i = rot ? w * c * gi : 0.0;
+        if (rot) flag = 1;
       }
-      __syncthreads();
+      // pending V <- V J of the previous step (columns pv, qv of this thread's rows)
+      {
+        double vr[NROW][2], vi[CPLX ? NROW : 1][2];
+#pragma unroll
+        for (int r = 0; r < NROW; ++r) {
+          const int i = kb + KSTRIDE * r;
+          vr[r][0] = Vr[i][pv]; vr[r][1] = Vr[i][qv];
+          if constexpr (CPLX) { vi[r][0] = Vi[i][pv]; vi[r][1] = Vi[i][qv]; }
+        }
+#pragma unroll
+        for (int r = 0; r < NROW; ++r) {
+          const int i = kb + KSTRIDE * r;
+          const double vpr = vr[r][0], vqr = vr[r][1];
+          if constexpr (!CPLX) {
+            Vr[i][pv] = cv * vpr - svr * vqr;
+            Vr[i][qv] = svr * vpr + cv * vqr;
+          } else {
+            const double vpi = vi[r][0], vqi = vi[r][1];
+            // new_p = c vp - conj(sg) vq ; new_q = sg vp + c vq
+            Vr[i][pv] = cv * vpr - (svr * vqr + svi * vqi);
+            Vi[i][pv] = cv * vpi - (svr * vqi - svi * vqr);
+            Vr[i][qv] = (svr * vpr - svi * vpi) + cv * vqr;
+            Vi[i][qv] = (svr * vpi + svi * vpr) + cv * vqi;
+          }
+        }
+      }
+      cv = c2; svr = s2r; svi = s2i; pv = p2; qv = q2;
 #ifdef XMCA_JAC_PROF
       if (PRELOADED && tid == 0 && step >= 1 && step < JAC_PROF_IT) jac_prof[((int)blockIdx.x * JAC_PROF_IT + step) * JAC_PROF_ST + 3] = (long long)__builtin_readcyclecounter();
 #endif
-      int p2, q2;
-      pair_of(k2, step, p2, q2);
-      const double c2 = rc[k2], s2r = rsr[k2], s2i = CPLX ? rsi[k2] : 0.0;
-      const bool id2 = (c2 == 1.0 && s2r == 0.0 && s2i == 0.0);
-      // M <- J^H M J as (NT/2)^2 independent 2x2 blocks, V <- V J on this thread's rows.  Everything is read into
-      // registers first and written back at the end: the blocks of one thread never overlap, but the compiler cannot
-      // know that, and a read-compute-write loop per block costs one LDS round trip per block (5 in a row; 3.6k
-      // cycles per step measured) on what is the serial path of the solver.  An identity rotation (c = 1, s = 0)
-      // reproduces its operands exactly, so no block is skipped.
+      // M <- J^H M J as (NT/2)^2 independent 2x2 blocks.  Everything is read into registers first and written back
+      // at the end: the blocks of one thread never overlap, but the compiler cannot know that, and a
+      // read-compute-write loop per block costs one LDS round trip per block on the serial path of the solver.  An
+      // identity rotation (c = 1, s = 0) reproduces its operands exactly, so no block is skipped.
       double mr[NBLK][4], mi[CPLX ? NBLK : 1][4];
-      double c1[NBLK], s1r[NBLK], s1i[NBLK];
       int p1[NBLK], q1[NBLK];
-      double vr[NROW][2], vi[CPLX ? NROW : 1][2];
 #pragma unroll
       for (int b = 0; b < NBLK; ++b) {
-        const int k1 = kb + KSTRIDE * b;
-        pair_of(k1, step, p1[b], q1[b]);
-        c1[b] = rc[k1]; s1r[b] = rsr[k1]; s1i[b] = CPLX ? rsi[k1] : 0.0;
+        pair_of(kb + KSTRIDE * b, step, p1[b], q1[b]);
         mr[b][0] = Mr[p1[b]][p2]; mr[b][1] = Mr[p1[b]][q2]; mr[b][2] = Mr[q1[b]][p2]; mr[b][3] = Mr[q1[b]][q2];
         if constexpr (CPLX) { mi[b][0] = Mi[p1[b]][p2]; mi[b][1] = Mi[p1[b]][q2]; mi[b][2] = Mi[q1[b]][p2]; mi[b][3] = Mi[q1[b]][q2]; }
       }
 #pragma unroll
-      for (int r = 0; r < NROW; ++r) {
-        const int i = kb + KSTRIDE * r;
-        vr[r][0] = Vr[i][p2]; vr[r][1] = Vr[i][q2];
-        if constexpr (CPLX) { vi[r][0] = Vi[i][p2]; vi[r][1] = Vi[i][q2]; }
-      }
-#pragma unroll
       for (int b = 0; b < NBLK; ++b) {
         const int k1 = kb + KSTRIDE * b;
+        const int src = k1 + (lane & ~(H - 1) & 31);   // a lane of this wave that holds rotation k1 (lane % H == k1)
+        const double cc = __shfl(c2, src), sr = __shfl(s2r, src), si = CPLX ? __shfl(s2i, src) : 0.0;
         const double b00r = mr[b][0], b01r = mr[b][1], b10r = mr[b][2], b11r = mr[b][3];
-        const double cc = c1[b], sr = s1r[b], si = s1i[b];
         if constexpr (!CPLX) {
           // rows: x0 = c1 b0 - s1 b1 ; x1 = s1 b0 + c1 b1
           const double x00 = cc * b00r - sr * b10r, x01 = cc * b01r - sr * b11r;
@@ -298,32 +315,12 @@ __device__ __forceinline__ void jacobi_tile_evd_body(JacTileSmem<NT, CPLX>& sm, 
           mi[b][0] = y00i; mi[b][1] = y01i; mi[b][2] = y10i; mi[b][3] = y11i;
         }
       }
-      // V <- V J   (columns p2, q2 of this thread's rows)
-#pragma unroll
-      for (int r = 0; r < NROW; ++r) {
-        const double vpr = vr[r][0], vqr = vr[r][1];
-        if constexpr (!CPLX) {
-          vr[r][0] = c2 * vpr - s2r * vqr;
-          vr[r][1] = s2r * vpr + c2 * vqr;
-        } else {
-          const double vpi = vi[r][0], vqi = vi[r][1];
-          // new_p = c vp - conj(sg) vq ; new_q = sg vp + c vq
-          vr[r][0] = c2 * vpr - (s2r * vqr + s2i * vqi);
-          vi[r][0] = c2 * vpi - (s2r * vqi - s2i * vqr);
-          vr[r][1] = (s2r * vpr - s2i * vpi) + c2 * vqr;
-          vi[r][1] = (s2r * vpi + s2i * vpr) + c2 * vqi;
-        }
-      }
+      // all M reads of this step (also the angle inputs of the other waves) must be done before anything is rewritten
+      __syncthreads();
 #pragma unroll
       for (int b = 0; b < NBLK; ++b) {
         Mr[p1[b]][p2] = mr[b][0]; Mr[p1[b]][q2] = mr[b][1]; Mr[q1[b]][p2] = mr[b][2]; Mr[q1[b]][q2] = mr[b][3];
         if constexpr (CPLX) { Mi[p1[b]][p2] = mi[b][0]; Mi[p1[b]][q2] = mi[b][1]; Mi[q1[b]][p2] = mi[b][2]; Mi[q1[b]][q2] = mi[b][3]; }
-      }
-#pragma unroll
-      for (int r = 0; r < NROW; ++r) {
-        const int i = kb + KSTRIDE * r;
-        Vr[i][p2] = vr[r][0]; Vr[i][q2] = vr[r][1];
-        if constexpr (CPLX) { Vi[i][p2] = vi[r][0]; Vi[i][q2] = vi[r][1]; }
       }
 #ifdef XMCA_JAC_PROF
       if (PRELOADED && tid == 0 && step >= 1 && step < JAC_PROF_IT) jac_prof[((int)blockIdx.x * JAC_PROF_IT + step) * JAC_PROF_ST + 4] = (long long)__builtin_readcyclecounter();
@@ -336,6 +333,25 @@ __device__ __forceinline__ void jacobi_tile_evd_body(JacTileSmem<NT, CPLX>& sm, 
     const int f = flag;
     __syncthreads();
     if (!f) break;
+  }
+  // the V update of the very last step
+  {
+#pragma unroll
+    for (int r = 0; r < NROW; ++r) {
+      const int i = kb + KSTRIDE * r;
+      const double vpr = Vr[i][pv], vqr = Vr[i][qv];
+      if constexpr (!CPLX) {
+        Vr[i][pv] = cv * vpr - svr * vqr;
+        Vr[i][qv] = svr * vpr + cv * vqr;
+      } else {
+        const double vpi = Vi[i][pv], vqi = Vi[i][qv];
+        Vr[i][pv] = cv * vpr - (svr * vqr + svi * vqi);
+        Vi[i][pv] = cv * vpi - (svr * vqi - svi * vqr);
+        Vr[i][qv] = (svr * vpr - svi * vpi) + cv * vqr;
+        Vi[i][qv] = (svr * vpi + svi * vpr) + cv * vqi;
+      }
+    }
+    __syncthreads();
   }
 
 #ifdef XMCA_JAC_PROF

@@ -14,6 +14,7 @@
 // and look at the state block only once per batch; the stop iteration is decided on the device.
 #pragma once
 #include "common.h"
+#include "gemm.h"
 #include "kernels.h"
 
 namespace xmca {
@@ -100,7 +101,10 @@ __device__ __forceinline__ void rot_accum_body(double* __restrict__ sm, const do
                                                const double* __restrict__ Rr, const double* __restrict__ Ri,
                                                const double* __restrict__ cvec, const double* __restrict__ colmax, double power,
                                                double* __restrict__ part_r, double* __restrict__ part_i,
-                                               unsigned long long* __restrict__ colmax_bits) {
+                                               unsigned long long* __restrict__ colmax_bits,
+                                               double* __restrict__ local_r = nullptr, double* __restrict__ local_i = nullptr,
+                                               double* __restrict__ res_r = nullptr, double* __restrict__ res_i = nullptr,
+                                               const bool res_ready = false) {
   // layout: Xs[p][LDP], Ys[p][LDP], Rs[p][p]  (x2 planes when complex), wgt[PB]
   const int pl = p * ROT_LDP;
   double* Xr = sm;
@@ -126,25 +130,35 @@ __device__ __forceinline__ void rot_accum_body(double* __restrict__ sm, const do
   const int64_t nbatch = (N + ROT_PB - 1) / ROT_PB;
   for (int64_t bt = blockIdx.x; bt < nbatch; bt += gridDim.x) {
     const int64_t n0 = bt * ROT_PB;
-    __syncthreads();
-    // stage the A tile into Ys (coalesced over grid points)
-    for (int e = tid; e < p * ROT_PB; e += 256) {
-      const int j = e / ROT_PB, pt = e % ROT_PB;
-      const int64_t n = n0 + pt;
-      double vr = 0.0, vi = 0.0;
-      if (n < N) {
-        vr = Ar[(int64_t)j * N + n];
-        if constexpr (CPLX) vi = Ai[(int64_t)j * N + n];
-      }
-      Yr[j * ROT_LDP + pt] = vr;
-      if constexpr (CPLX) Yi[j * ROT_LDP + pt] = vi;
+    // persistent caller: the A tiles of this workgroup stay in LDS (res_*) for the whole loop and are staged once
+    double* Ybr = Yr;
+    double* Ybi = Yi;
+    if (res_r) {
+      const int64_t bl = (bt - blockIdx.x) / gridDim.x;
+      Ybr = res_r + bl * pl;
+      Ybi = res_i + bl * pl;
     }
     __syncthreads();
+    if (!res_r || !res_ready) {
+      // stage the A tile (coalesced over grid points)
+      for (int e = tid; e < p * ROT_PB; e += 256) {
+        const int j = e / ROT_PB, pt = e % ROT_PB;
+        const int64_t n = n0 + pt;
+        double vr = 0.0, vi = 0.0;
+        if (n < N) {
+          vr = Ar[(int64_t)j * N + n];
+          if constexpr (CPLX) vi = Ai[(int64_t)j * N + n];
+        }
+        Ybr[j * ROT_LDP + pt] = vr;
+        if constexpr (CPLX) Ybi[j * ROT_LDP + pt] = vi;
+      }
+      __syncthreads();
+    }
     if (MODE == 1) {
       for (int e = tid; e < p * ROT_PB; e += 256) {
         const int j = e / ROT_PB, pt = e % ROT_PB;
-        Xr[j * ROT_LDP + pt] = Yr[j * ROT_LDP + pt];
-        if constexpr (CPLX) Xi[j * ROT_LDP + pt] = Yi[j * ROT_LDP + pt];
+        Xr[j * ROT_LDP + pt] = Ybr[j * ROT_LDP + pt];
+        if constexpr (CPLX) Xi[j * ROT_LDP + pt] = Ybi[j * ROT_LDP + pt];
       }
       __syncthreads();
     } else {
@@ -152,10 +166,10 @@ __device__ __forceinline__ void rot_accum_body(double* __restrict__ sm, const do
       for (int k = wave; k < p; k += 4) {
         double zr = 0.0, zi = 0.0;
         for (int j = 0; j < p; ++j) {
-          const double ar = Yr[j * ROT_LDP + lane], rr = Rsr[j * p + k];
+          const double ar = Ybr[j * ROT_LDP + lane], rr = Rsr[j * p + k];
           zr += ar * rr;
           if constexpr (CPLX) {
-            const double ai = Yi[j * ROT_LDP + lane], ri = Rsi[j * p + k];
+            const double ai = Ybi[j * ROT_LDP + lane], ri = Rsi[j * p + k];
             zr -= ai * ri;
             zi += ar * ri + ai * rr;
           }
@@ -224,8 +238,8 @@ __device__ __forceinline__ void rot_accum_body(double* __restrict__ sm, const do
     }
     // out[j][k] += sum_pt w(pt) conj(L_j(pt)) * Q_k(pt)
     //   MODE 0: L = A (Ys), Q = W (Xs) ; MODE 1: L = Q = A ; MODE 2: L = X, Q = X (SEL 0,2,3) or Y (SEL 1)
-    const double* Lr = (MODE == 0) ? Yr : Xr;
-    const double* Li = (MODE == 0) ? Yi : Xi;
+    const double* Lr = (MODE == 0) ? Ybr : Xr;
+    const double* Li = (MODE == 0) ? Ybi : Xi;
     const double* Qr = (MODE == 2 && SEL == 1) ? Yr : Xr;
     const double* Qi = (MODE == 2 && SEL == 1) ? Yi : Xi;
 #pragma unroll
@@ -256,9 +270,14 @@ __device__ __forceinline__ void rot_accum_body(double* __restrict__ sm, const do
   for (int sl = 0; sl < MAXE; ++sl) {
     const int e = tid + 256 * sl;
     if (e < p * p) {
-      const int64_t idx = (int64_t)blockIdx.x * p * p + e;
-      part_r[idx] = accr[sl];
-      if constexpr (CPLX) part_i[idx] = acci[sl];
+      if (local_r) {   // persistent caller: the partial stays in this workgroup's LDS
+        local_r[e] = accr[sl];
+        if constexpr (CPLX) local_i[e] = acci[sl];
+      } else {
+        const int64_t idx = (int64_t)blockIdx.x * p * p + e;
+        part_r[idx] = accr[sl];
+        if constexpr (CPLX) part_i[idx] = acci[sl];
+      }
     }
   }
 }
@@ -587,7 +606,89 @@ __global__ __launch_bounds__(256) void varimax_step_kernel(const double* __restr
 // convergence; 11-20 iterations for cond(G) <= 1e4), and d = sum(s) = Re tr(R^H G) - first-order insensitive to
 // errors in R because R^H dR is skew-Hermitian.  Same R and d as rotation.py:59-61 to rounding, no SVD.
 // ---------------------------------------------------------------------------------------------------------------
+#ifdef XMCA_ROT_PROF
+__device__ long long rot_prof[16];
+#define ROT_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) rot_prof[k] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define ROT_STAMP(k) do { } while (0)
+#endif
+
 static inline size_t rot_polar_smem(int p, bool cplx) { return sizeof(double) * ((cplx ? 2 : 1) * 4 * (size_t)p * p + 1024); }
+
+// Newton-Schulz for p <= 16 by ONE wave with everything in registers.  X (padded to 16 x 16) lives in the C/D layout
+// of v_mfma_f64_16x16x4_f64 (lane l, register r <-> entry [l/16 + 4r][l%16]), and so does its plain transpose Xt.
+// With that layout  S(P, Q) = sum_r mfma(P[r], Q[r]) = P^T Q  for any two such register sets (the k index of MFMA
+// number r is taken to be the row l/16 + 4r - a permutation of the summation order), so
+//     T = X^H X :  Tr = S(Xr,Xr) + S(Xi,Xi),   Ti = S(Xr,Xi) - S(Xi,Xr)
+//     Y = X T   :  Yr = S(Xtr,Tr) - S(Xti,Ti), Yi = S(Xtr,Ti) + S(Xti,Tr)
+//     Y^T       :  Ytr = S(Tr,Xtr) - S(Ti,Xti), Yti = S(Ti,Xtr) + S(Tr,Xti)        (Tr symmetric, Ti antisymmetric)
+// need no transposition, no LDS and no barrier: 12 (real) / 48 (complex) MFMAs per iteration.
+// Returns the iteration count, or -1 (NaN / no convergence).  Call with one full wave; X goes to Xr/Xi (p x p).
+template <bool CPLX>
+__device__ __forceinline__ int varimax_ns_wave16(const double* __restrict__ Gr, const double* __restrict__ Gi, const int p,
+                                                 const double inv, double* __restrict__ Xr, double* __restrict__ Xi) {
+  const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+  double xr[4], xtr[4], xi[4], xti[4];
+  bool in[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = l4 + 4 * r, col = l15;
+    in[r] = row < p && col < p;
+    xr[r] = in[r] ? Gr[row * p + col] * inv : 0.0;
+    xtr[r] = in[r] ? Gr[col * p + row] * inv : 0.0;
+    xi[r] = (CPLX && in[r]) ? Gi[row * p + col] * inv : 0.0;
+    xti[r] = (CPLX && in[r]) ? Gi[col * p + row] * inv : 0.0;
+  }
+  auto S = [](const double (&P)[4], const double (&Q)[4], d4_t acc, const double sign) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc = Mfma<double>::mma(sign * P[r], Q[r], acc);
+    return acc;
+  };
+  const d4_t zero = {0, 0, 0, 0};
+  int it = 0;
+  for (; it < 100; ++it) {
+    d4_t tr = S(xr, xr, zero, 1.0), ti = zero;
+    if constexpr (CPLX) {
+      tr = S(xi, xi, tr, 1.0);
+      ti = S(xr, xi, zero, 1.0);
+      ti = S(xi, xr, ti, -1.0);
+    }
+    bool bad = false;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double err = fmax(fabs(tr[r] - ((l4 + 4 * r == l15) ? 1.0 : 0.0)), fabs(ti[r]));
+      if (in[r] && !(err < 1e-14)) bad = true;
+    }
+    if (!__any(bad)) break;
+    double trr[4] = {tr[0], tr[1], tr[2], tr[3]}, tii[4] = {ti[0], ti[1], ti[2], ti[3]};
+    d4_t yr = S(xtr, trr, zero, 1.0), yi = zero, ytr = S(trr, xtr, zero, 1.0), yti = zero;
+    if constexpr (CPLX) {
+      yr = S(xti, tii, yr, -1.0);
+      yi = S(xtr, tii, zero, 1.0);
+      yi = S(xti, trr, yi, 1.0);
+      ytr = S(tii, xti, ytr, -1.0);
+      yti = S(tii, xtr, zero, 1.0);
+      yti = S(trr, xti, yti, 1.0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      xr[r] = 1.5 * xr[r] - 0.5 * yr[r];
+      xtr[r] = 1.5 * xtr[r] - 0.5 * ytr[r];
+      if constexpr (CPLX) {
+        xi[r] = 1.5 * xi[r] - 0.5 * yi[r];
+        xti[r] = 1.5 * xti[r] - 0.5 * yti[r];
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (in[r]) {
+      Xr[(l4 + 4 * r) * p + l15] = xr[r];
+      if constexpr (CPLX) Xi[(l4 + 4 * r) * p + l15] = xi[r];
+    }
+  }
+  return it < 100 ? it : -1;
+}
 
 template <bool CPLX>
 __device__ void varimax_polar_step(double* __restrict__ sm, const double* __restrict__ part_r, const double* __restrict__ part_i,
@@ -616,54 +717,64 @@ __device__ void varimax_polar_step(double* __restrict__ sm, const double* __rest
     return take_max ? fmax(fmax(a, b), fmax(c, d)) : (a + b) + (c + d);
   };
 
-  // G = sum of partials (fixed order): pp <= 128 uses 256 / pp thread slices per entry
+  // G = sum of partials, always in the same order: thread slice sl of entry e adds the workgroups sl, sl + nsl, ...
+  // (16 loads in flight - the partials come from L2 after the acquire), the slices are then added in order.
   const int nsl = pp <= 128 ? 256 / pp : 1;
+  double fro2 = 0.0;
   if (nsl > 1) {
     const int sl = tid / pp, e = tid % pp;
     if (sl < nsl) {
-      // 8 loads in flight per thread (the partials sit in L2; a dependent chain would cost ~1 us per load)
-      double ar[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ai[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int w = sl; w < nwg; w += 8 * nsl) {
+      double sr = 0.0, si = 0.0;
+      for (int w0 = sl; w0 < nwg; w0 += 16 * nsl) {
+        double vr[16], vi[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int ww = w + u * nsl;
-          if (ww < nwg) {
-            ar[u] += part_r[(int64_t)ww * pp + e];
-            if constexpr (CPLX) ai[u] += part_i[(int64_t)ww * pp + e];
-          }
+        for (int u = 0; u < 16; ++u) {
+          const int ww = w0 + u * nsl;
+          vr[u] = ww < nwg ? part_r[(int64_t)ww * pp + e] : 0.0;
+          if constexpr (CPLX) vi[u] = ww < nwg ? part_i[(int64_t)ww * pp + e] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          sr += vr[u];
+          if constexpr (CPLX) si += vi[u];
         }
       }
-      scr[tid] = ((ar[0] + ar[1]) + (ar[2] + ar[3])) + ((ar[4] + ar[5]) + (ar[6] + ar[7]));
-      if constexpr (CPLX) scr[256 + tid] = ((ai[0] + ai[1]) + (ai[2] + ai[3])) + ((ai[4] + ai[5]) + (ai[6] + ai[7]));
+      scr[tid] = sr;
+      if constexpr (CPLX) scr[256 + tid] = si;
     }
     __syncthreads();
-  }
-  double fro2 = 0.0;
-  for (int e = tid; e < pp; e += 256) {
-    double sr = 0.0, si = 0.0;
-    if (nsl > 1) {
-      for (int sl = 0; sl < nsl; ++sl) {
-        sr += scr[sl * pp + e];
-        if constexpr (CPLX) si += scr[256 + sl * pp + e];
+    for (int e2 = tid; e2 < pp; e2 += 256) {
+      double sr = 0.0, si = 0.0;
+      for (int s2 = 0; s2 < nsl; ++s2) {
+        sr += scr[s2 * pp + e2];
+        if constexpr (CPLX) si += scr[256 + s2 * pp + e2];
       }
-    } else {
-      double ar[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ai[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int w = 0; w < nwg; w += 8) {
+      Gr[e2] = sr;
+      fro2 += sr * sr;
+      if constexpr (CPLX) { Gi[e2] = si; fro2 += si * si; }
+    }
+  } else {
+    for (int e = tid; e < pp; e += 256) {
+      double sr = 0.0, si = 0.0;
+      for (int w0 = 0; w0 < nwg; w0 += 16) {
+        double vr[16], vi[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          if (w + u < nwg) {
-            ar[u] += part_r[(int64_t)(w + u) * pp + e];
-            if constexpr (CPLX) ai[u] += part_i[(int64_t)(w + u) * pp + e];
-          }
+        for (int u = 0; u < 16; ++u) {
+          vr[u] = w0 + u < nwg ? part_r[(int64_t)(w0 + u) * pp + e] : 0.0;
+          if constexpr (CPLX) vi[u] = w0 + u < nwg ? part_i[(int64_t)(w0 + u) * pp + e] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          sr += vr[u];
+          if constexpr (CPLX) si += vi[u];
         }
       }
-      sr = ((ar[0] + ar[1]) + (ar[2] + ar[3])) + ((ar[4] + ar[5]) + (ar[6] + ar[7]));
-      si = ((ai[0] + ai[1]) + (ai[2] + ai[3])) + ((ai[4] + ai[5]) + (ai[6] + ai[7]));
+      Gr[e] = sr;
+      fro2 += sr * sr;
+      if constexpr (CPLX) { Gi[e] = si; fro2 += si * si; }
     }
-    Gr[e] = sr;
-    fro2 += sr * sr;
-    if constexpr (CPLX) { Gi[e] = si; fro2 += si * si; }
   }
+  ROT_STAMP(3);
   fro2 = block_reduce(fro2, false);
   const double inv = 1.0 / sqrt(fro2);
   for (int e = tid; e < pp; e += 256) {
@@ -672,52 +783,72 @@ __device__ void varimax_polar_step(double* __restrict__ sm, const double* __rest
   }
   __syncthreads();
 
-  // Newton-Schulz with two barriers per iteration: X and Y alternate roles (no copy), the convergence measure of
-  // iteration k is reduced per wave and read by everybody after the barrier that also publishes T.
+  // Newton-Schulz with two barriers per iteration: X and Y alternate roles (no copy); "some entry of X^H X is still
+  // 1e-14 away from I" is a flag in LDS that the barrier publishing T makes visible (no reduction tree), and the
+  // (j, k) of a thread's first entry is computed once (a 32-bit division per matmul is as long as the matmul).
   int it = 0;
   bool ok = false;
   double* Cr = Xr;   // current iterate
   double* Ci = Xi;
   double* Nr = Yr;   // next iterate
   double* Ni = Yi;
-  for (; it < 100; ++it) {
-    double err = 0.0;
+  const int j0 = tid / p, k0 = tid % p;
+  int* nsflag = reinterpret_cast<int*>(scr + 1008);    // [0..1]: "not converged" by parity, [2]: NaN seen, [3]: wave16 result
+  if (tid < 3) nsflag[tid] = 0;
+  __syncthreads();
+  static_assert(ROT_PMAX >= 16, "");
+  if (p <= 16) {
+    // register-resident MFMA form; it restarts from G (the scaled copy in X is not needed)
+    if (tid < 64) {
+      const int n_it = varimax_ns_wave16<CPLX>(Gr, Gi, p, inv, Xr, Xi);
+      if (tid == 0) nsflag[3] = n_it;
+    }
+    __syncthreads();
+    it = nsflag[3];
+    ok = it >= 0;
+    if (!ok) it = 100;
+  }
+  for (; p > 16 && it < 100; ++it) {
     for (int e = tid; e < pp; e += 256) {
-      const int j = e / p, k = e % p;
+      const int j = (e == tid) ? j0 : e / p, k = (e == tid) ? k0 : e % p;
       double tr = 0.0, ti = 0.0;
+      const double* cj = Cr + j;
+      const double* ck = Cr + k;
+      const double* dj = Ci + j;
+      const double* dk = Ci + k;
 #pragma unroll 5
       for (int m = 0; m < p; ++m) {
-        const double ar = Cr[m * p + j], br = Cr[m * p + k];
+        const double ar = cj[m * p], br = ck[m * p];
         tr += ar * br;
         if constexpr (CPLX) {
-          const double ai = Ci[m * p + j], bi = Ci[m * p + k];
+          const double ai = dj[m * p], bi = dk[m * p];
           tr += ai * bi;                 // conj(a) b
           ti += ar * bi - ai * br;
         }
       }
       Tr[e] = tr;
       if constexpr (CPLX) Ti[e] = ti;
-      err = fmax(err, fmax(fabs(tr - (j == k ? 1.0 : 0.0)), fabs(ti)));
-      if (!(tr == tr)) err = HUGE_VAL;
+      const double err = fmax(fabs(tr - (j == k ? 1.0 : 0.0)), fabs(ti));
+      if (!(err < 1e-14)) nsflag[it & 1] = 1;
+      if (!(tr == tr) || !(ti == ti) || err == HUGE_VAL) nsflag[2] = 1;
     }
-    for (int o = 32; o > 0; o >>= 1) err = fmax(err, __shfl_xor(err, o));
-    if ((tid & 63) == 0) scr[1000 + 4 * (it & 1) + (tid >> 6)] = err;
+    if (tid == 0) nsflag[(it + 1) & 1] = 0;   // next iteration's flag (its last reader passed the previous barrier)
     __syncthreads();
-    {
-      const double* e4 = scr + 1000 + 4 * (it & 1);
-      err = fmax(fmax(e4[0], e4[1]), fmax(e4[2], e4[3]));
-    }
-    if (!(err < HUGE_VAL)) break;        // NaN / inf
-    if (err < 1e-14) { ok = true; break; }
+    if (nsflag[2]) break;                       // NaN / inf
+    if (!nsflag[it & 1]) { ok = true; break; }
     for (int e = tid; e < pp; e += 256) {
-      const int j = e / p, k = e % p;
+      const int j = (e == tid) ? j0 : e / p, k = (e == tid) ? k0 : e % p;
       double yr = 0.0, yi = 0.0;
+      const double* xj = Cr + j * p;
+      const double* yj = Ci + j * p;
+      const double* tk = Tr + k;
+      const double* uk = Ti + k;
 #pragma unroll 5
       for (int m = 0; m < p; ++m) {
-        const double xr = Cr[j * p + m], t_r = Tr[m * p + k];
+        const double xr = xj[m], t_r = tk[m * p];
         yr += xr * t_r;
         if constexpr (CPLX) {
-          const double xi = Ci[j * p + m], t_i = Ti[m * p + k];
+          const double xi = yj[m], t_i = uk[m * p];
           yr -= xi * t_i;
           yi += xr * t_i + xi * t_r;
         }
@@ -729,6 +860,7 @@ __device__ void varimax_polar_step(double* __restrict__ sm, const double* __rest
     { double* t = Cr; Cr = Nr; Nr = t; }
     { double* t = Ci; Ci = Ni; Ni = t; }
   }
+  ROT_STAMP(4);
   if (Cr != Xr) {   // the tail below expects the converged factor in X
     for (int e = tid; e < pp; e += 256) {
       Xr[e] = Cr[e];
@@ -776,6 +908,7 @@ __device__ void varimax_polar_step(double* __restrict__ sm, const double* __rest
     state[2] = dsum;
     state[0] += 1.0;
     state[5] = (double)it;
+    ROT_STAMP(5);
     if (!ok || !(dsum == dsum)) state[4] = 1.0;                  // NaN / singular G
     else if (fabs(dsum - d_old) / dsum < tol) state[1] = 1.0;    // rotation.py:62
   }
@@ -790,7 +923,13 @@ __global__ __launch_bounds__(256) void varimax_iter_kernel(const double* __restr
   if (state[1] != 0.0 || state[4] != 0.0) return;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* sm = reinterpret_cast<double*>(smem_raw);
+#ifdef XMCA_ROT_PROF
+  const long long t_start = (long long)__builtin_readcyclecounter();
+#endif
   rot_accum_body<CPLX, 0, 0>(sm, Ar, Ai, h, N, N, p, Rr, Ri, cvec, nullptr, 1.0, part_r, part_i, nullptr);
+#ifdef XMCA_ROT_PROF
+  const long long t_acc = (long long)__builtin_readcyclecounter();
+#endif
   // publish the partial, take a ticket (release before, acquire after: placement independent)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -808,7 +947,269 @@ __global__ __launch_bounds__(256) void varimax_iter_kernel(const double* __restr
   }
   __syncthreads();
   if (!is_last) return;
+#ifdef XMCA_ROT_PROF
+  if (threadIdx.x == 0 && blockIdx.x == 0) { rot_prof[0] = t_start; rot_prof[1] = t_acc; }
+#endif
+  ROT_STAMP(2);
   varimax_polar_step<CPLX>(sm, part_r, part_i, (int)gridDim.x, p, A0r, A0i, Rr, Ri, cvec, state, tol);
+}
+
+// MFMA form of the Varimax accumulation (MODE 0 of rot_accum_body) for the persistent kernel:
+//   Z = A R (64 grid points x p per tile),  W = (|Z|^2 - c/N) Z,  G += A^H W
+// as v_mfma_f64_16x16x4_f64 products on 16-wide mode tiles (PT = ceil(p/16) per dimension).  Wave w computes the Z rows
+// of points 16w..16w+15; the G tiles are split over the waves (PT >= 2) or, when there is a single tile, the 64
+// points are (4 partial tiles, added in wave order).  The accumulators stay in registers over all tiles of the
+// workgroup.  LDS: Xs = W[k][pt], tiles = A[j][pt] (both pitch ROT_LDP: conflict-free operand reads), Rs = R[j][k].
+template <bool CPLX>
+__device__ __forceinline__ void varimax_accum_mfma(double* __restrict__ sm, const double* __restrict__ Ar,
+                                                   const double* __restrict__ Ai, const int64_t N, const int p,
+                                                   const double* __restrict__ Rr, const double* __restrict__ Ri,
+                                                   const double* __restrict__ cvec, double* __restrict__ out_r,
+                                                   double* __restrict__ out_i, double* __restrict__ res_r,
+                                                   double* __restrict__ res_i, const bool res_ready) {
+  const int pl = p * ROT_LDP, pp = p * p;
+  double* Xr = sm;
+  double* Yr = Xr + pl;
+  double* Rsr = Yr + pl;
+  double* wgt = Rsr + pp;
+  double* Xi = wgt + ROT_PB;
+  double* Yi = Xi + pl;
+  double* Rsi = Yi + pl;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+  const int PT = (p + 15) / 16;
+  constexpr int MAXT = 4;                 // G tiles per wave: ceil(PT^2 / 4) <= 4
+  for (int e = tid; e < pp; e += 256) {
+    Rsr[e] = Rr[e];
+    if constexpr (CPLX) Rsi[e] = Ri[e];
+  }
+  double cn[MAXT];                        // c_k / N for this lane's column of mode tile kt
+#pragma unroll
+  for (int kt = 0; kt < MAXT; ++kt) {
+    const int k = kt * 16 + l15;
+    cn[kt] = (kt < PT && k < p) ? cvec[k] / (double)N : 0.0;
+  }
+  d4_t gr[MAXT], gi[MAXT];
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) { gr[t] = d4_t{0, 0, 0, 0}; gi[t] = d4_t{0, 0, 0, 0}; }
+  const bool ksplit = PT == 1;
+
+  const int64_t nbatch = (N + ROT_PB - 1) / ROT_PB;
+  for (int64_t bt = blockIdx.x; bt < nbatch; bt += gridDim.x) {
+    const int64_t n0 = bt * ROT_PB;
+    double* Tr = Yr;
+    double* Ti = Yi;
+    if (res_r) {
+      const int64_t bl = (bt - blockIdx.x) / gridDim.x;
+      Tr = res_r + bl * pl;
+      Ti = res_i + bl * pl;
+    }
+    __syncthreads();
+    if (!res_r || !res_ready) {
+      for (int e = tid; e < p * ROT_PB; e += 256) {
+        const int j = e / ROT_PB, pt = e % ROT_PB;
+        const int64_t n = n0 + pt;
+        double vr = 0.0, vi = 0.0;
+        if (n < N) {
+          vr = Ar[(int64_t)j * N + n];
+          if constexpr (CPLX) vi = Ai[(int64_t)j * N + n];
+        }
+        Tr[j * ROT_LDP + pt] = vr;
+        if constexpr (CPLX) Ti[j * ROT_LDP + pt] = vi;
+      }
+      __syncthreads();
+    }
+    // Z rows of this wave's 16 points, one mode tile at a time; W goes to Xs
+    for (int kt = 0; kt < PT; ++kt) {
+      d4_t zr = {0, 0, 0, 0}, zi = {0, 0, 0, 0};
+      const int k = kt * 16 + l15;
+      for (int j0 = 0; j0 < p; j0 += 4) {
+        const int j = j0 + l4;
+        const bool jin = j < p, kin = jin && k < p;
+        const int ja = jin ? j : 0, ka = k < p ? k : 0;
+        double ar = Tr[ja * ROT_LDP + wave * 16 + l15], br = Rsr[ja * p + ka];
+        ar = jin ? ar : 0.0;
+        br = kin ? br : 0.0;
+        zr = Mfma<double>::mma(ar, br, zr);
+        if constexpr (CPLX) {
+          double ai = Ti[ja * ROT_LDP + wave * 16 + l15], bi = Rsi[ja * p + ka];
+          ai = jin ? ai : 0.0;
+          bi = kin ? bi : 0.0;
+          zr = Mfma<double>::mma(-ai, bi, zr);
+          zi = Mfma<double>::mma(ar, bi, zi);
+          zi = Mfma<double>::mma(ai, br, zi);
+        }
+      }
+      if (k < p) {
+        double cnk = cn[0];
+#pragma unroll
+        for (int q = 1; q < MAXT; ++q) cnk = (kt == q) ? cn[q] : cnk;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          // W = (|z|^2 - c_k / N) z     (rotation.py:56-57)
+          const double f = zr[r] * zr[r] + zi[r] * zi[r] - cnk;
+          const int pt = wave * 16 + l4 + 4 * r;
+          Xr[k * ROT_LDP + pt] = f * zr[r];
+          if constexpr (CPLX) Xi[k * ROT_LDP + pt] = f * zi[r];
+        }
+      }
+    }
+    __syncthreads();
+    // G[j][k] += sum_pt conj(A[pt][j]) W[pt][k]
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      const int tile = ksplit ? 0 : wave + 4 * t;
+      if ((ksplit && t > 0) || tile >= PT * PT) continue;
+      const int jt = tile / PT, kt = tile % PT;
+      const int j = jt * 16 + l15, k = kt * 16 + l15;
+      const bool jin = j < p, kin = k < p;
+      const int ja = jin ? j : 0, ka = kin ? k : 0;
+      const int pbeg = ksplit ? wave * 16 : 0, pend = ksplit ? wave * 16 + 16 : ROT_PB;
+      d4_t ar4 = gr[t], ai4 = gi[t];
+      for (int pt0 = pbeg; pt0 < pend; pt0 += 4) {
+        double ar = Tr[ja * ROT_LDP + pt0 + l4], wr = Xr[ka * ROT_LDP + pt0 + l4];
+        ar = jin ? ar : 0.0;
+        wr = kin ? wr : 0.0;
+        ar4 = Mfma<double>::mma(ar, wr, ar4);
+        if constexpr (CPLX) {
+          double ai = Ti[ja * ROT_LDP + pt0 + l4], wi = Xi[ka * ROT_LDP + pt0 + l4];
+          ai = jin ? ai : 0.0;
+          wi = kin ? wi : 0.0;
+          ar4 = Mfma<double>::mma(ai, wi, ar4);      // conj(a) w
+          ai4 = Mfma<double>::mma(ar, wi, ai4);
+          ai4 = Mfma<double>::mma(-ai, wr, ai4);
+        }
+      }
+      gr[t] = ar4;
+      gi[t] = ai4;
+    }
+  }
+  __syncthreads();      // Xs / tiles are no longer read: the scratch below may overlap them
+  if (ksplit) {
+    double* scr_r = sm;                 // [wave][p][p]
+    double* scr_i = sm + 4 * pp;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = l4 + 4 * r, k = l15;
+      if (j < p && k < p) {
+        scr_r[wave * pp + j * p + k] = gr[0][r];
+        if constexpr (CPLX) scr_i[wave * pp + j * p + k] = gi[0][r];
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < pp; e += 256) {
+      out_r[e] = ((scr_r[e] + scr_r[pp + e]) + scr_r[2 * pp + e]) + scr_r[3 * pp + e];
+      if constexpr (CPLX) out_i[e] = ((scr_i[e] + scr_i[pp + e]) + scr_i[2 * pp + e]) + scr_i[3 * pp + e];
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      const int tile = wave + 4 * t;
+      if (tile >= PT * PT) continue;
+      const int jt = tile / PT, kt = tile % PT;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = jt * 16 + l4 + 4 * r, k = kt * 16 + l15;
+        if (j < p && k < p) {
+          out_r[j * p + k] = gr[t][r];
+          if constexpr (CPLX) out_i[j * p + k] = gi[t][r];
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The whole Varimax loop in ONE launch.  Every workgroup keeps R, c and the iteration state in its own LDS; per
+// iteration it (1) accumulates its partial G over its share of the grid points, (2) publishes it (write-through
+// stores + one epoch flag per workgroup; cdna_hip_programming.md G16 form R1), (3) waits for the flags of all
+// workgroups, takes one agent-scope acquire and (4) reduces the partials in a fixed order and runs the polar step
+// itself.  All workgroups execute the same arithmetic on the same numbers, so they agree on R and on the stopping
+// iteration without a second exchange.  Payload buffers alternate with the epoch parity: a workgroup can be at most
+// one epoch ahead of the slowest one, because epoch e+1 cannot be completed by anybody before everybody published it.
+// The grid must be resident (<= one workgroup per CU is requested by the host); every spin is bounded.
+// ---------------------------------------------------------------------------------------------------------------
+static inline size_t rot_persistent_smem(int p, bool cplx) {
+  return std::max(rot_accum_smem(p, cplx), rot_polar_smem(p, cplx)) + sizeof(double) * (6 * (size_t)p * p + p + ROT_STATE_N + 8);
+}
+// LDS for keeping `nb` A tiles (64 grid points each) resident
+static inline size_t rot_resident_smem(int p, bool cplx, int nb) { return sizeof(double) * (cplx ? 2 : 1) * (size_t)nb * p * ROT_LDP; }
+
+template <bool CPLX>
+__global__ __launch_bounds__(256) void varimax_persistent_kernel(const double* __restrict__ Ar, const double* __restrict__ Ai,
+                                                                 const double* __restrict__ h, int64_t N, int p,
+                                                                 const double* __restrict__ A0r, const double* __restrict__ A0i,
+                                                                 double* Rr, double* Ri, double* cvec, double* state, double* part_r,
+                                                                 double* part_i, unsigned int* flags, double tol, int max_iter,
+                                                                 size_t work_doubles, int resident_tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* sm = reinterpret_cast<double*>(smem_raw);          // accumulate / polar scratch (time-shared)
+  const int pp = p * p, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nwg = (int)gridDim.x, bid = (int)blockIdx.x;
+  double* Rl_r = sm + work_doubles;
+  double* Rl_i = Rl_r + pp;
+  double* acc_r = Rl_i + pp;
+  double* acc_i = acc_r + pp;
+  double* a0_r = acc_i + pp;
+  double* a0_i = a0_r + pp;
+  double* cl = a0_i + pp;
+  double* stl = cl + p;
+  double* res_r = resident_tiles > 0 ? stl + ROT_STATE_N + 8 : nullptr;      // [tile][p][ROT_LDP], then the imaginary planes
+  double* res_i = (CPLX && resident_tiles > 0) ? res_r + (size_t)resident_tiles * p * ROT_LDP : res_r;
+  __shared__ int give_up;
+  for (int e = tid; e < pp; e += 256) {
+    Rl_r[e] = Rr[e];
+    Rl_i[e] = CPLX ? Ri[e] : 0.0;
+    a0_r[e] = A0r[e];
+    a0_i[e] = CPLX ? A0i[e] : 0.0;
+  }
+  for (int e = tid; e < p; e += 256) cl[e] = cvec[e];
+  if (tid < ROT_STATE_N) stl[tid] = state[tid];
+  if (tid == 0) give_up = 0;
+  __syncthreads();
+
+  for (int it = 0; it < max_iter; ++it) {
+    if (stl[1] != 0.0 || stl[4] != 0.0) break;                // converged / NaN: identical in every workgroup
+    const unsigned int epoch = (unsigned int)it + 1u;
+    double* pub_r = part_r + (size_t)(it & 1) * nwg * pp;
+    double* pub_i = CPLX ? part_i + (size_t)(it & 1) * nwg * pp : nullptr;
+    ROT_STAMP(0);
+    varimax_accum_mfma<CPLX>(sm, Ar, Ai, N, p, Rl_r, Rl_i, cl, acc_r, acc_i, res_r, res_i, it > 0);
+    __syncthreads();
+    ROT_STAMP(1);
+    for (int e = tid; e < pp; e += 256) {
+      __hip_atomic_store(pub_r + (size_t)bid * pp + e, acc_r[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if constexpr (CPLX) __hip_atomic_store(pub_i + (size_t)bid * pp + e, acc_i[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every storing wave drains before the flag goes out
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flags + bid, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ROT_STAMP(6);
+    if (wave == 0) {
+      unsigned int spins = 0;
+      for (;;) {
+        bool ok = true;
+        for (int w = lane; w < nwg; w += 64) ok &= __hip_atomic_load(flags + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch;
+        if (__all(ok)) break;
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 22)) { if (lane == 0) give_up = 1; break; }   // a workgroup is missing: report, never hang
+      }
+      ROT_STAMP(7);
+      if (lane == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (give_up) { if (tid == 0) stl[4] = 2.0; __syncthreads(); break; }
+    ROT_STAMP(2);
+    varimax_polar_step<CPLX>(sm, pub_r, pub_i, nwg, p, a0_r, a0_i, Rl_r, Rl_i, cl, stl, tol);
+    __syncthreads();
+  }
+  if (bid == 0) {
+    for (int e = tid; e < pp; e += 256) {
+      Rr[e] = Rl_r[e];
+      if constexpr (CPLX) Ri[e] = Rl_i[e];
+    }
+    for (int e = tid; e < p; e += 256) cvec[e] = cl[e];
+    if (tid < ROT_STATE_N) state[tid] = stl[tid];
+  }
 }
 
 // B[n][k] = scale_n * sum_j a_j(n) M[j][k]   ->  N x p row-major (interleaved complex) for the host

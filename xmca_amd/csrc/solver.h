@@ -638,6 +638,8 @@ struct RotationDevice {
   CPlanes A, R, A0, acc, W;   // W: right singular vectors of the previous Varimax step (warm start)
   DevBuf<double> h, cvec, state, part_r, part_i, colmax;
   DevBuf<unsigned int> counter;     // arrival ticket of the fused Varimax iteration kernel
+  DevBuf<unsigned int> pflags;      // persistent Varimax kernel: epoch flag per workgroup
+  DevBuf<double> ppart_r, ppart_i;  // ... and its double-buffered partials
   int64_t N = 0, Nleft = 0;
   int p = 0;
   bool cplx = false;
@@ -652,7 +654,10 @@ class Rotator {
 
   static int pick_nwg(int64_t N) {
     const int64_t nb = (N + ROT_PB - 1) / ROT_PB;
-    return (int)std::max<int64_t>(1, std::min<int64_t>(nb, 128));
+    static const int cap = [] { const char* e = std::getenv("XMCA_ROT_WGS"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 128; }();
+    // equal shares: with 157 tiles and a cap of 128 workgroups, 79 workgroups of 2 tiles beat 128 of 1-2
+    const int64_t per = (nb + cap - 1) / cap;
+    return (int)std::max<int64_t>(1, (nb + per - 1) / per);
   }
 
   template <bool CPLX, int MODE, int SEL>
@@ -711,6 +716,31 @@ class Rotator {
     if (fused)
       XMCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(varimax_iter_kernel<CPLX>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_smem));
+    // XMCA_VARIMAX_PERSIST (default on): the whole loop in one launch, workgroups exchange their partial G through
+    // epoch-tagged buffers.  Needs a resident grid (<= 1 workgroup per CU) and the LDS for both scratch areas.
+    static const bool persist_on = [] { const char* e = std::getenv("XMCA_VARIMAX_PERSIST"); return !(e && e[0] == '0'); }();
+    const size_t work_bytes = std::max(rot_accum_smem(p, CPLX), rot_polar_smem(p, CPLX));
+    size_t persist_smem = rot_persistent_smem(p, CPLX);
+    const int tiles_per_wg = (int)(((d.N + ROT_PB - 1) / ROT_PB + d.nwg - 1) / d.nwg);
+    const bool resident = persist_smem + rot_resident_smem(p, CPLX, tiles_per_wg) <= 160 * 1024;
+    if (resident) persist_smem += rot_resident_smem(p, CPLX, tiles_per_wg);
+    if (fused && persist_on && persist_smem <= 160 * 1024 && d.nwg <= 256 && max_iter > 0) {
+      d.pflags.ensure((size_t)d.nwg);
+      d.ppart_r.ensure((size_t)2 * d.nwg * p * p);
+      if (CPLX) d.ppart_i.ensure((size_t)2 * d.nwg * p * p);
+      XMCA_HIP(hipMemsetAsync(d.pflags.get(), 0, sizeof(unsigned int) * d.nwg, st));
+      XMCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(varimax_persistent_kernel<CPLX>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_smem));
+      hipLaunchKernelGGL((varimax_persistent_kernel<CPLX>), dim3(d.nwg), dim3(256), persist_smem, st, d.A.r(), d.A.i(CPLX), d.h.get(),
+                         d.N, p, d.A0.r(), d.A0.i(CPLX), d.R.r(), d.R.i(CPLX), d.cvec.get(), d.state.get(), d.ppart_r.get(),
+                         CPLX ? d.ppart_i.get() : nullptr, d.pflags.get(), tol, max_iter, work_bytes / sizeof(double),
+                         resident ? tiles_per_wg : 0);
+      XMCA_HIP(hipGetLastError());
+      XMCA_HIP(hipMemcpyAsync(state, d.state.get(), sizeof(state), hipMemcpyDeviceToHost, st));
+      XMCA_HIP(hipStreamSynchronize(st));
+      XMCA_CHECK(state[4] != 2.0, XMCA_ERR_HIP, "varimax: a workgroup of the persistent kernel never arrived (grid not resident?)");
+      launched = max_iter;
+    }
     while (launched < max_iter) {
       const int batch = std::min(32, max_iter - launched);
       for (int b = 0; b < batch; ++b) {
@@ -735,6 +765,14 @@ class Rotator {
       if (state[1] != 0.0 || state[4] != 0.0) break;
     }
     tm.end();
+#ifdef XMCA_ROT_PROF
+    {
+      long long hs[16];
+      XMCA_HIP(hipMemcpyFromSymbol(hs, HIP_SYMBOL(rot_prof), sizeof(hs)));
+      std::fprintf(stderr, "[xmca varimax prof] accum %lld  publish %lld  wait %lld  acquire %lld  reduce %lld  newton-schulz %lld (its %g)  tail %lld  total %lld cycles (nwg %d)\n",
+                   hs[1] - hs[0], hs[6] - hs[1], hs[7] - hs[6], hs[2] - hs[7], hs[3] - hs[2], hs[4] - hs[3], state[5], hs[5] - hs[4], hs[5] - hs[0], d.nwg);
+    }
+#endif
     res.iters = (int)state[0];
     res.converged = state[1] != 0.0;
     res.nan = state[4] != 0.0;
