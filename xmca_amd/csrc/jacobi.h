@@ -1174,6 +1174,25 @@ __global__ void jacobi_diag_kernel(const double* __restrict__ Gr, int npad, doub
   if (i < npad) d[i] = Gr[(int64_t)i * npad + i];
 }
 
+// Largest off-diagonal entry (relative to the matrix scale, entries at the rotation floor ignored) of the state a
+// sweep leaves behind.  Only the block-upper triangle of half-blocks is maintained by the fused rounds.
+__global__ void jacobi_offmax_kernel(const double* __restrict__ Gr, const double* __restrict__ Gi, int npad, int hb,
+                                     const double* __restrict__ scal, unsigned long long* __restrict__ out) {
+  const double gscale = scal[0], floor2 = scal[1] * scal[1];
+  double mx = 0.0;
+  const int64_t total = (int64_t)npad * npad;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(idx / npad), c = (int)(idx % npad);
+    if (r == c || r / hb > c / hb) continue;
+    double g2 = Gr[idx] * Gr[idx];
+    if (Gi) g2 += Gi[idx] * Gi[idx];
+    if (!(g2 == g2)) mx = HUGE_VAL;
+    else if (g2 > floor2) mx = fmax(mx, sqrt(g2) / gscale);
+  }
+  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+  if ((threadIdx.x & 63) == 0 && mx > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(mx));
+}
+
 // Zs[i][0..n) = Z[perm[i]][0..n)
 __global__ void jacobi_gather_kernel(const double* __restrict__ Zr, const double* __restrict__ Zi, int npad,
                                      const int* __restrict__ perm, int n, double* __restrict__ Or, double* __restrict__ Oi,
@@ -1254,7 +1273,7 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
   ws.scal.ensure(2);
   ws.off.ensure(JAC_OFF_RING);
   ws.perm.ensure((size_t)npad);
-  if (max_sweeps > JAC_OFF_RING - 1) max_sweeps = JAC_OFF_RING - 1;
+  if (max_sweeps > JAC_OFF_RING - 2) max_sweeps = JAC_OFF_RING - 2;   // the last slot holds the post-sweep measure
 
   XMCA_HIP(hipMemsetAsync(ws.off.get(), 0, sizeof(unsigned long long) * JAC_OFF_RING, st));
   hipLaunchKernelGGL(jacobi_init_scale_kernel, dim3(1), dim3(256), 0, st, Ar, n, lda, tol, ws.scal.get());
@@ -1336,14 +1355,26 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
       cur ^= 1;
     }
     XMCA_HIP(hipGetLastError());
-    unsigned long long bits = 0;
-    XMCA_HIP(hipMemcpyAsync(&bits, ws.off.get() + sweep, sizeof(bits), hipMemcpyDeviceToHost, st));
+    // two measures per sweep: `off` = the largest entry the sweep met when it visited the tiles (also carries the NaN
+    // flag), `left` = the largest entry of the matrix it leaves behind (one 25 us pass).  Stopping on `left` saves the
+    // sweep that would only confirm convergence.
+    unsigned long long bits[2] = {0, 0};
+    if (S > 1) {
+      XMCA_HIP(hipMemsetAsync(ws.off.get() + JAC_OFF_RING - 1, 0, sizeof(unsigned long long), st));
+      hipLaunchKernelGGL(jacobi_offmax_kernel, dim3(2048), dim3(256), 0, st, ws.G[cur][0].get(), CPLX ? ws.G[cur][1].get() : nullptr,
+                         npad, NT / 2, ws.scal.get(), ws.off.get() + JAC_OFF_RING - 1);
+      XMCA_HIP(hipMemcpyAsync(&bits[1], ws.off.get() + JAC_OFF_RING - 1, sizeof(bits[1]), hipMemcpyDeviceToHost, st));
+    }
+    XMCA_HIP(hipMemcpyAsync(&bits[0], ws.off.get() + sweep, sizeof(bits[0]), hipMemcpyDeviceToHost, st));
     XMCA_HIP(hipStreamSynchronize(st));
-    std::memcpy(&off, &bits, sizeof(double));
+    std::memcpy(&off, &bits[0], sizeof(double));
+    double left = off;
+    if (S > 1) std::memcpy(&left, &bits[1], sizeof(double));
     ++sweeps;
     static const bool trace = std::getenv("XMCA_JACOBI_TRACE") != nullptr;
-    if (trace) std::fprintf(stderr, "[xmca jacobi] n=%d NT=%d cplx=%d sweep %d: max off/scale seen = %.3e\n", n, NT, (int)CPLX, sweeps, off);
+    if (trace) std::fprintf(stderr, "[xmca jacobi] n=%d NT=%d cplx=%d sweep %d: max off/scale seen = %.3e, left = %.3e\n", n, NT, (int)CPLX, sweeps, off, left);
     if (S == 1 || !(off >= tol) || !std::isfinite(off)) break;
+    if (left < tol) { off = left; break; }
   }
   XMCA_CHECK(std::isfinite(off), XMCA_ERR_NUMERIC, "SVD failed. NaN entries may be the problem.");
 #ifdef XMCA_JAC_PROF
