@@ -118,6 +118,24 @@ def main():
                 "algorithmic_bytes": 8.0 * (T * N + T * T)}
 
     extra = {}
+    # ---- the T x T eigensolver ("latency bound; report ms and achieved GF/s informally") ----
+    # one launch of jacobi_fused_round_kernel per round; per round every upper tile of G (two 64^3 products) and every
+    # eigenvector tile (one product) is read and written once
+    info = stages["eigh_info"]
+    if info.get("slots", 0) > 1 and info.get("sweeps", 0) > 0:
+        S, nt = info["slots"], info["tile"]
+        rounds = info["sweeps"] * (2 * S - 1)
+        flops_round = (S * (S - 1) // 2) * 2 * 2.0 * nt ** 3 + S * S * 2.0 * nt ** 3
+        bytes_round = 2.0 * 8.0 * nt * nt * (S * (S + 1) // 2 + S * S)
+        us_round = 1e3 * stages["eigh"] / rounds
+        extra["eigensolver"] = {"kernel": "jacobi_fused_round_kernel<64,real> (one launch per round)", "rounds": rounds,
+                                "us_per_round_incl_init_and_gather": us_round,
+                                "algorithmic_flops_per_round": flops_round, "achieved_TFLOPs": flops_round / us_round / 1e6,
+                                "frac_of_f64_mfma_peak": flops_round / us_round / 1e6 / F64_MFMA_PEAK_TF,
+                                "algorithmic_bytes_per_round": bytes_round, "achieved_GBs": bytes_round / us_round / 1e3,
+                                "frac_of_hbm_peak": bytes_round / us_round / 1e3 / 8000.0}
+    if stages.get("varimax") and out.get("n_iter"):
+        extra["varimax_us_per_iteration"] = 1e3 * stages["varimax"] / out["n_iter"]
     # cheap self-check of the timed result (full parity against the oracle is in cpu_baseline/parity and tests/)
     Vt = h.vectors(0, args.n_rot, N, X.dtype)
     proj = X @ Vt.T

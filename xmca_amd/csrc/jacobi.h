@@ -1180,15 +1180,18 @@ __global__ void jacobi_offmax_kernel(const double* __restrict__ Gr, const double
                                      const double* __restrict__ scal, unsigned long long* __restrict__ out) {
   const double gscale = scal[0], floor2 = scal[1] * scal[1];
   double mx = 0.0;
-  const int64_t total = (int64_t)npad * npad;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    const int r = (int)(idx / npad), c = (int)(idx % npad);
-    if (r == c || r / hb > c / hb) continue;
-    double g2 = Gr[idx] * Gr[idx];
-    if (Gi) g2 += Gi[idx] * Gi[idx];
-    if (!(g2 == g2)) mx = HUGE_VAL;
-    else if (g2 > floor2) mx = fmax(mx, sqrt(g2) / gscale);
+  // one row per block (grid-stride over rows), columns from the row's own half-block on
+  for (int r = blockIdx.x; r < npad; r += gridDim.x) {
+    const int64_t row = (int64_t)r * npad;
+    for (int c = (r / hb) * hb + threadIdx.x; c < npad; c += blockDim.x) {
+      if (c == r) continue;
+      double g2 = Gr[row + c] * Gr[row + c];
+      if (Gi) g2 += Gi[row + c] * Gi[row + c];
+      if (!(g2 == g2)) mx = HUGE_VAL;
+      else if (g2 > floor2) mx = fmax(mx, g2);
+    }
   }
+  if (mx < HUGE_VAL) mx = sqrt(mx) / gscale;
   for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
   if ((threadIdx.x & 63) == 0 && mx > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(mx));
 }
