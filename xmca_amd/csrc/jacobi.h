@@ -159,8 +159,9 @@ __device__ __forceinline__ void jacobi_tile_evd_body(JacTileSmem<NT, CPLX>& sm, 
     __syncthreads();
   }
 
-  // off-diagonal measure of this tile before it is touched (drives the outer sweep loop)
-  {
+  // off-diagonal measure of this tile before it is touched (trace / single-tile problems; the outer loop stops on
+  // jacobi_offmax_kernel).  Not on the serial path of the fused rounds: PRELOADED callers skip it.
+  if constexpr (!PRELOADED) {
     double mx = 0.0;
     for (int e = tid; e < NT * NT; e += 256) {
       const int i = e / NT, j = e % NT;
@@ -168,7 +169,7 @@ __device__ __forceinline__ void jacobi_tile_evd_body(JacTileSmem<NT, CPLX>& sm, 
         double g2 = Mr[i][j] * Mr[i][j];
         if constexpr (CPLX) g2 += Mi[i][j] * Mi[i][j];
         if (!(g2 == g2)) mx = HUGE_VAL;                       // NaN in the matrix: reported to the host as +inf
-        else if (i < j && g2 > abs_floor * abs_floor) mx = fmax(mx, sqrt(g2) / gscale);
+        else if (i < j && g2 > abs_floor * abs_floor) mx = fmax(mx, g2);
       }
     }
     for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
@@ -176,6 +177,7 @@ __device__ __forceinline__ void jacobi_tile_evd_body(JacTileSmem<NT, CPLX>& sm, 
     __syncthreads();
     if (tid == 0) {
       mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+      if (mx < HUGE_VAL) mx = sqrt(mx) / gscale;
       if (mx > 0.0) atomicMax(sweep_off, (unsigned long long)__double_as_longlong(mx));
     }
   }
@@ -813,7 +815,7 @@ struct JacItem {
   int kind, P, Q, nsub;
 };
 
-__device__ __forceinline__ JacItem jacobi_decode_item(int id, const int S, const int n_off, const int zch) {
+__device__ __forceinline__ JacItem jacobi_decode_item(int id, const int S, const int n_off, const int zch, const int zw) {
   JacItem it;
   it.kind = -1; it.P = 0; it.Q = 0; it.nsub = 0;
   if (id < 0) return it;
@@ -828,8 +830,8 @@ __device__ __forceinline__ JacItem jacobi_decode_item(int id, const int S, const
   if (id < S * zch) {
     it.kind = 2;
     it.P = id / zch;
-    it.Q = (id % zch) * 2;
-    it.nsub = min(2, S - it.Q);
+    it.Q = (id % zch) * zw;
+    it.nsub = min(zw, S - it.Q);
     return it;
   }
   id -= S * zch;
@@ -859,7 +861,7 @@ __device__ __forceinline__ void jacobi_persistent_update(JacUpdSmem<NT, CPLX>& s
                                                          double* __restrict__ Zr_out, double* __restrict__ Zi_out,
                                                          const double* __restrict__ Jr, const double* __restrict__ Ji,
                                                          const double* __restrict__ Dr, const double* __restrict__ Di, const int S,
-                                                         const int ld, const int zch) {
+                                                         const int ld, const int zch, const int zw) {
   constexpr int HB = NT / 2;
   constexpr int TPD = NT / 16;
   constexpr int NACC = TPD * TPD / 4;
@@ -1017,7 +1019,7 @@ __device__ __forceinline__ void jacobi_persistent_update(JacUpdSmem<NT, CPLX>& s
     slot[3] = (int)atomicAdd(counter, 1u);
   }
   __syncthreads();
-  JacItem cur = jacobi_decode_item(__builtin_amdgcn_readfirstlane(slot[2]), S, n_off, zch);
+  JacItem cur = jacobi_decode_item(__builtin_amdgcn_readfirstlane(slot[2]), S, n_off, zch, zw);
   int nxt_id = __builtin_amdgcn_readfirstlane(slot[3]);
   issue_PT(cur);
   issue_Q(cur);
@@ -1027,7 +1029,7 @@ __device__ __forceinline__ void jacobi_persistent_update(JacUpdSmem<NT, CPLX>& s
     if (tid == 0 && iter < JAC_PROF_IT && blockIdx.x < JAC_PROF_WG) jac_prof[((int)blockIdx.x * JAC_PROF_IT + iter) * JAC_PROF_ST + 9] = cur.kind;
 #endif
     if (tid == 0) pending = atomicAdd(counter, 1u);    // the item after next; consumed at the bottom of this iteration
-    const JacItem nxt = jacobi_decode_item(nxt_id, S, n_off, zch);
+    const JacItem nxt = jacobi_decode_item(nxt_id, S, n_off, zch, zw);
     if (cur.kind == 0) {
       // the diagonal tile was transformed by the tile solver itself (D_P = J_P^H G[P,P] J_P): move it to its destination
       // quarters.  Nothing reads a half-block below the block diagonal again (tiles are taken from the upper triangle,
@@ -1065,25 +1067,30 @@ __device__ __forceinline__ void jacobi_persistent_update(JacUpdSmem<NT, CPLX>& s
         __syncthreads();
         JAC_STAMP(5);
         const int P = cur.P, Q = cur.Q;
-        // each quarter goes out once, in the orientation that lies above the block diagonal of the next round:
-        // as it is (element (r, c) of Y), or conjugate-transposed (this thread then plays row' = c-index, col' = r-index)
-        const int bq = jacobi_dest_block(Q, col / HB, S), bp = jacobi_dest_block(P, col / HB, S);
-        const unsigned int voff_n = (unsigned int)(row0 * ld + bq * HB + col % HB) * 8u;
-        const unsigned int voff_m = (unsigned int)(row0 * ld + bp * HB + col % HB) * 8u;
+        // each quarter (hr, hc) goes out once, in the orientation that lies above the block diagonal of the next round
+        // (uniform per quarter): as it is, or conjugate-transposed.  Either way a wave writes full row segments.
+        constexpr int QR = 256 / HB;          // quarter rows per pass
+        constexpr int QP = HB / QR;           // passes per quarter
+        const int qrow = tid / HB, qcol = tid % HB;
+        const unsigned int voff_q = (unsigned int)(qrow * ld + qcol) * 8u;
 #pragma unroll
-        for (int i = 0; i < EPT; ++i) {
-          const int h = (RP * i) / HB, rin = (RP * i) % HB;
-          const int br = jacobi_dest_block(P, h, S);
-          if (br < bq) {
-            const unsigned int soff = (unsigned int)((br * HB + rin) * ld) * 8u;
-            jac_st(Br[row0 + RP * i][col], oGr, voff_n, soff);
-            if constexpr (CPLX) jac_st(Bi[row0 + RP * i][col], oGi, voff_n, soff);
-          }
-          const int bc2 = jacobi_dest_block(Q, h, S);
-          if (bp > bc2) {
-            const unsigned int soff = (unsigned int)((bc2 * HB + rin) * ld) * 8u;
-            jac_st(Br[col][row0 + RP * i], oGr, voff_m, soff);
-            if constexpr (CPLX) jac_st(-Bi[col][row0 + RP * i], oGi, voff_m, soff);
+        for (int q = 0; q < 4; ++q) {
+          const int hr = q >> 1, hc = q & 1;
+          const int br = jacobi_dest_block(P, hr, S), bc = jacobi_dest_block(Q, hc, S);
+          if (br < bc) {
+#pragma unroll
+            for (int ps = 0; ps < QP; ++ps) {
+              const unsigned int soff = (unsigned int)((br * HB + QR * ps) * ld + bc * HB) * 8u;
+              jac_st(Br[hr * HB + qrow + QR * ps][hc * HB + qcol], oGr, voff_q, soff);
+              if constexpr (CPLX) jac_st(Bi[hr * HB + qrow + QR * ps][hc * HB + qcol], oGi, voff_q, soff);
+            }
+          } else {
+#pragma unroll
+            for (int ps = 0; ps < QP; ++ps) {
+              const unsigned int soff = (unsigned int)((bc * HB + QR * ps) * ld + br * HB) * 8u;
+              jac_st(Br[hr * HB + qcol][hc * HB + qrow + QR * ps], oGr, voff_q, soff);
+              if constexpr (CPLX) jac_st(-Bi[hr * HB + qcol][hc * HB + qrow + QR * ps], oGi, voff_q, soff);
+            }
           }
         }
       } else {
@@ -1122,7 +1129,7 @@ __global__ __launch_bounds__(256, 2) void jacobi_fused_round_kernel(const double
                                                                     double* Jr_next, double* Ji_next, double* Dr_next,
                                                                     double* Di_next, double tol, const double* scal,
                                                                     unsigned long long* sweep_off, int max_sweeps, int cross_only,
-                                                                    int S, int ld, unsigned int* work_counter, int zch,
+                                                                    int S, int ld, unsigned int* work_counter, int zch, int zw,
                                                                     unsigned int* cu_table, unsigned int tag) {
   __shared__ union U {
     JacTileSmem<NT, CPLX> t;
@@ -1166,7 +1173,7 @@ __global__ __launch_bounds__(256, 2) void jacobi_fused_round_kernel(const double
   return;
 #endif
   jacobi_persistent_update<NT, CPLX>(sm.u, slot, work_counter, Gr_in, Gi_in, Gr_out, Gi_out, Zr_in, Zi_in, Zr_out, Zi_out, Jr, Ji, Dr,
-                                     Di, S, ld, zch);
+                                     Di, S, ld, zch, zw);
 }
 
 __global__ void jacobi_diag_kernel(const double* __restrict__ Gr, int npad, double* __restrict__ d) {
@@ -1315,7 +1322,8 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
   };
 
   // fused rounds: persistent workgroups (two per CU) pull items from one counter per round
-  const int zch2 = want_z ? (S + 1) / 2 : 0;
+  static const int zw = [] { const char* e = std::getenv("XMCA_JAC_ZW"); return (e && e[0] == '2') ? 2 : 1; }();   // eigenvector tiles per work item: singles balance the tail better
+  const int zch2 = want_z ? (S + zw - 1) / zw : 0;
   const int fused_items = n_off + S * zch2 + S;
   static const int resident_wgs = [] {
     int dev = 0, cus = 256;
@@ -1352,7 +1360,7 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
                            CPLX ? ws.J[par][1].get() : nullptr, ws.D[par][0].get(), CPLX ? ws.D[par][1].get() : nullptr,
                            ws.J[par ^ 1][0].get(), CPLX ? ws.J[par ^ 1][1].get() : nullptr, ws.D[par ^ 1][0].get(),
                            CPLX ? ws.D[par ^ 1][1].get() : nullptr, tile_tol, ws.scal.get(), ws.off.get() + next_slot,
-                           inner_cap, is_cross((r + 1) % rounds) ? 1 : 0, S, npad, ws.work.get() + round_no, zch2,
+                           inner_cap, is_cross((r + 1) % rounds) ? 1 : 0, S, npad, ws.work.get() + round_no, zch2, zw,
                            exclusive_on ? ws.cu_table.get() : nullptr, (unsigned int)(round_no + 1));
       }
       cur ^= 1;
@@ -1376,8 +1384,8 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
     ++sweeps;
     static const bool trace = std::getenv("XMCA_JACOBI_TRACE") != nullptr;
     if (trace) std::fprintf(stderr, "[xmca jacobi] n=%d NT=%d cplx=%d sweep %d: max off/scale seen = %.3e, left = %.3e\n", n, NT, (int)CPLX, sweeps, off, left);
-    if (S == 1 || !(off >= tol) || !std::isfinite(off)) break;
-    if (left < tol) { off = left; break; }
+    if (S == 1) break;
+    if (!(left >= tol) || !std::isfinite(left)) { off = left; break; }
   }
   XMCA_CHECK(std::isfinite(off), XMCA_ERR_NUMERIC, "SVD failed. NaN entries may be the problem.");
 #ifdef XMCA_JAC_PROF
