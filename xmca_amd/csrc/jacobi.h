@@ -834,9 +834,7 @@ __device__ __forceinline__ JacItem jacobi_decode_item(int id, const int S, const
     it.nsub = min(zw, S - it.Q);
     return it;
   }
-  id -= S * zch;
-  if (id < S) { it.kind = 0; it.P = id; }
-  return it;
+  return it;      // past the end: kind -1
 }
 
 typedef unsigned int jac_u32x2 __attribute__((ext_vector_type(2)));
@@ -861,7 +859,8 @@ __device__ __forceinline__ void jacobi_persistent_update(JacUpdSmem<NT, CPLX>& s
                                                          double* __restrict__ Zr_out, double* __restrict__ Zi_out,
                                                          const double* __restrict__ Jr, const double* __restrict__ Ji,
                                                          const double* __restrict__ Dr, const double* __restrict__ Di, const int S,
-                                                         const int ld, const int zch, const int zw) {
+                                                         const int ld, const int zch, const int n_static, const int worker,
+                                                         const int n_workers) {
   constexpr int HB = NT / 2;
   constexpr int TPD = NT / 16;
   constexpr int NACC = TPD * TPD / 4;
@@ -925,8 +924,6 @@ __device__ __forceinline__ void jacobi_persistent_update(JacUpdSmem<NT, CPLX>& s
   };
   auto issue_Q = [&](const JacItem& it) {
     if (it.kind == 1) fetch(tQ, rJr, rJi, voff_J, (unsigned int)(it.Q * NT * NT), 256u);
-    else if (it.kind == 2 && it.nsub == 2)
-      fetch(tQ, rZr, rZi, voff_T, (unsigned int)(it.P * NT * ld + (it.Q + 1) * NT), (unsigned int)(RP * ld));
   };
   // B <- A^H B   (A = J_P, B = tile), through registers
   auto mul_AhB = [&]() {
@@ -1011,32 +1008,11 @@ __device__ __forceinline__ void jacobi_persistent_update(JacUpdSmem<NT, CPLX>& s
     }
   };
 
-  // slot[2], slot[3]: the first two item ids; slot[0], slot[1]: alternate per iteration, so that the single barrier at
-  // the bottom of the loop is enough (a slot is rewritten two iterations after it was read)
-  unsigned int pending = 0;
-  if (tid == 0) {
-    slot[2] = (int)atomicAdd(counter, 1u);
-    slot[3] = (int)atomicAdd(counter, 1u);
-  }
-  __syncthreads();
-  JacItem cur = jacobi_decode_item(__builtin_amdgcn_readfirstlane(slot[2]), S, n_off, zch, zw);
-  int nxt_id = __builtin_amdgcn_readfirstlane(slot[3]);
-  issue_PT(cur);
-  issue_Q(cur);
-  for (int iter = 0; cur.kind >= 0; ++iter) {
-    JAC_STAMP(0);
-#ifdef XMCA_JAC_PROF
-    if (tid == 0 && iter < JAC_PROF_IT && blockIdx.x < JAC_PROF_WG) jac_prof[((int)blockIdx.x * JAC_PROF_IT + iter) * JAC_PROF_ST + 9] = cur.kind;
-#endif
-    if (tid == 0) pending = atomicAdd(counter, 1u);    // the item after next; consumed at the bottom of this iteration
-    const JacItem nxt = jacobi_decode_item(nxt_id, S, n_off, zch, zw);
-    if (cur.kind == 0) {
-      // the diagonal tile was transformed by the tile solver itself (D_P = J_P^H G[P,P] J_P): move it to its destination
-      // quarters.  Nothing reads a half-block below the block diagonal again (tiles are taken from the upper triangle,
-      // diagonal tiles from D), so only the upper ones are written.
-      issue_PT(nxt);
-      issue_Q(nxt);
-      const int P = cur.P;
+  // ---- diagonal tiles: transformed by the tile solver itself (D_P = J_P^H G[P,P] J_P); the workers move them to their
+  // destination quarters.  Nothing reads a half-block below the block diagonal again (tiles are taken from the upper
+  // triangle, diagonal tiles from D), so only the upper ones are written.
+  if (worker >= 0) {
+    for (int P = worker; P < S; P += n_workers) {
       const int bc = jacobi_dest_block(P, col / HB, S);
       const unsigned int voff = (unsigned int)(row0 * ld + bc * HB + col % HB) * 8u;
 #pragma unroll
@@ -1049,72 +1025,122 @@ __device__ __forceinline__ void jacobi_persistent_update(JacUpdSmem<NT, CPLX>& s
           if constexpr (CPLX) jac_st(jac_ld(rDi, voff_J, src), oGi, voff, soff);
         }
       }
-    } else {
-      to_A(tP);
-      to_B(tT);
-      JAC_STAMP(1);
-      __syncthreads();
-      JAC_STAMP(2);
-      issue_PT(nxt);
-      mul_AhB();          // B = X = J_P^H T  (contains the barrier between reading and overwriting B)
-      JAC_STAMP(3);
-      if (cur.kind == 1) {
-        to_A(tQ);         // J_P is dead: every wave passed the barrier inside mul_AhB
-        __syncthreads();
-        JAC_STAMP(4);
-        issue_Q(nxt);
-        mul_BA();         // B = Y = X J_Q
-        __syncthreads();
-        JAC_STAMP(5);
-        const int P = cur.P, Q = cur.Q;
-        // each quarter (hr, hc) goes out once, in the orientation that lies above the block diagonal of the next round
-        // (uniform per quarter): as it is, or conjugate-transposed.  Either way a wave writes full row segments.
-        constexpr int QR = 256 / HB;          // quarter rows per pass
-        constexpr int QP = HB / QR;           // passes per quarter
-        const int qrow = tid / HB, qcol = tid % HB;
-        const unsigned int voff_q = (unsigned int)(qrow * ld + qcol) * 8u;
+    }
+  }
+
+  // ---- item sequence of this workgroup.  A worker (a workgroup that is not busy with a tile solve) takes, without any
+  // communication, the G tiles worker, worker + W, ... and then its static share of the eigenvector tiles (handed out in
+  // reverse worker order, which evens out the extra G tile some workers get).  What is left of the eigenvector tiles -
+  // and everything the late-joining solver workgroups do - is claimed from the counter.  A claim costs an L2 round trip
+  // that the compiler waits for on the spot (vmcnt(0): it would also wait for the prefetch in flight), so only the
+  // items that balance the tail pay it.
+  const int W = n_workers;
+  const int n_g_w = (worker >= 0 && worker < n_off) ? (n_off - worker + W - 1) / W : 0;
+  const int n_z_w = worker >= 0 ? n_static : 0;
+  const int dyn_base = n_off + n_static * W;
+  auto static_id = [&](const int k) { return k < n_g_w ? worker + k * W : n_off + (W - 1 - worker) + (k - n_g_w) * W; };
+  const int n_stat = n_g_w + n_z_w;
+  // slot[2], slot[3]: the first two item ids; slot[0], slot[1]: alternate per iteration, so that the single barrier at
+  // the bottom of an iteration is enough (a slot is rewritten two iterations after it was read)
+  unsigned int pending = 0;
+  if (tid == 0) {
+    slot[2] = n_stat > 0 ? static_id(0) : dyn_base + (int)atomicAdd(counter, 1u);
+    slot[3] = n_stat > 1 ? static_id(1) : dyn_base + (int)atomicAdd(counter, 1u);
+  }
+  __syncthreads();
+  JacItem cur = jacobi_decode_item(__builtin_amdgcn_readfirstlane(slot[2]), S, n_off, zch, 1);
+  int nxt_id = __builtin_amdgcn_readfirstlane(slot[3]);
+  issue_PT(cur);
+  issue_Q(cur);
+  int iter = 0;
+
+  // ---- G tiles: two products, three operand tiles.  The loop body is straight-line (one kind of item): the prefetch
+  // registers keep their place and the compiler's waits stay where the data is needed.
+  while (cur.kind == 1) {
+    JAC_STAMP(0);
+#ifdef XMCA_JAC_PROF
+    if (tid == 0 && iter < JAC_PROF_IT && blockIdx.x < JAC_PROF_WG) jac_prof[((int)blockIdx.x * JAC_PROF_IT + iter) * JAC_PROF_ST + 9] = 1;
+#endif
+    const JacItem nxt = jacobi_decode_item(nxt_id, S, n_off, zch, 1);
+    to_A(tP);
+    to_B(tT);
+    JAC_STAMP(1);
+    __syncthreads();
+    JAC_STAMP(2);
+    issue_PT(nxt);      // the next G tile, or the first eigenvector tile
+    mul_AhB();          // B = X = J_P^H T  (contains the barrier between reading and overwriting B)
+    JAC_STAMP(3);
+    to_A(tQ);           // J_P is dead: every wave passed the barrier inside mul_AhB
+    if (tid == 0 && iter + 2 >= n_stat) pending = dyn_base + atomicAdd(counter, 1u);
+    __syncthreads();
+    JAC_STAMP(4);
+    issue_Q(nxt);
+    mul_BA();           // B = Y = X J_Q
+    __syncthreads();
+    JAC_STAMP(5);
+    {
+      const int P = cur.P, Q = cur.Q;
+      // each quarter (hr, hc) goes out once, in the orientation that lies above the block diagonal of the next round
+      // (uniform per quarter): as it is, or conjugate-transposed.  Either way a wave writes full row segments.
+      constexpr int QR = 256 / HB;          // quarter rows per pass
+      constexpr int QP = HB / QR;           // passes per quarter
+      const int qrow = tid / HB, qcol = tid % HB;
+      const unsigned int voff_q = (unsigned int)(qrow * ld + qcol) * 8u;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int hr = q >> 1, hc = q & 1;
-          const int br = jacobi_dest_block(P, hr, S), bc = jacobi_dest_block(Q, hc, S);
-          if (br < bc) {
+      for (int q = 0; q < 4; ++q) {
+        const int hr = q >> 1, hc = q & 1;
+        const int br = jacobi_dest_block(P, hr, S), bc = jacobi_dest_block(Q, hc, S);
+        if (br < bc) {
 #pragma unroll
-            for (int ps = 0; ps < QP; ++ps) {
-              const unsigned int soff = (unsigned int)((br * HB + QR * ps) * ld + bc * HB) * 8u;
-              jac_st(Br[hr * HB + qrow + QR * ps][hc * HB + qcol], oGr, voff_q, soff);
-              if constexpr (CPLX) jac_st(Bi[hr * HB + qrow + QR * ps][hc * HB + qcol], oGi, voff_q, soff);
-            }
-          } else {
-#pragma unroll
-            for (int ps = 0; ps < QP; ++ps) {
-              const unsigned int soff = (unsigned int)((bc * HB + QR * ps) * ld + br * HB) * 8u;
-              jac_st(Br[hr * HB + qcol][hc * HB + qrow + QR * ps], oGr, voff_q, soff);
-              if constexpr (CPLX) jac_st(-Bi[hr * HB + qcol][hc * HB + qrow + QR * ps], oGi, voff_q, soff);
-            }
+          for (int ps = 0; ps < QP; ++ps) {
+            const unsigned int soff = (unsigned int)((br * HB + QR * ps) * ld + bc * HB) * 8u;
+            jac_st(Br[hr * HB + qrow + QR * ps][hc * HB + qcol], oGr, voff_q, soff);
+            if constexpr (CPLX) jac_st(Bi[hr * HB + qrow + QR * ps][hc * HB + qcol], oGi, voff_q, soff);
           }
-        }
-      } else {
-        __syncthreads();
-        store_z(cur.P, cur.Q);
-        if (cur.nsub == 2) {
-          __syncthreads();
-          to_B(tQ);
-          __syncthreads();
-          issue_Q(nxt);
-          mul_AhB();
-          __syncthreads();
-          store_z(cur.P, cur.Q + 1);
         } else {
-          issue_Q(nxt);
+#pragma unroll
+          for (int ps = 0; ps < QP; ++ps) {
+            const unsigned int soff = (unsigned int)((bc * HB + QR * ps) * ld + br * HB) * 8u;
+            jac_st(Br[hr * HB + qcol][hc * HB + qrow + QR * ps], oGr, voff_q, soff);
+            if constexpr (CPLX) jac_st(-Bi[hr * HB + qcol][hc * HB + qrow + QR * ps], oGi, voff_q, soff);
+          }
         }
       }
     }
     JAC_STAMP(6);
-    if (tid == 0) slot[iter & 1] = (int)pending;
+    if (tid == 0) slot[iter & 1] = (iter + 2 < n_stat) ? static_id(iter + 2) : (int)pending;
     __syncthreads();       // the LDS tiles are free again and the slot is visible
     JAC_STAMP(7);
     cur = nxt;
     nxt_id = __builtin_amdgcn_readfirstlane(slot[iter & 1]);
+    ++iter;
+  }
+
+  // ---- eigenvector tiles: one product, two operand tiles
+  while (cur.kind == 2) {
+    JAC_STAMP(0);
+#ifdef XMCA_JAC_PROF
+    if (tid == 0 && iter < JAC_PROF_IT && blockIdx.x < JAC_PROF_WG) jac_prof[((int)blockIdx.x * JAC_PROF_IT + iter) * JAC_PROF_ST + 9] = 2;
+#endif
+    const JacItem nxt = jacobi_decode_item(nxt_id, S, n_off, zch, 1);
+    to_A(tP);
+    to_B(tT);
+    JAC_STAMP(1);
+    __syncthreads();
+    JAC_STAMP(2);
+    issue_PT(nxt);
+    mul_AhB();
+    JAC_STAMP(3);
+    if (tid == 0 && iter + 2 >= n_stat) pending = dyn_base + atomicAdd(counter, 1u);
+    __syncthreads();
+    store_z(cur.P, cur.Q);
+    JAC_STAMP(6);
+    if (tid == 0) slot[iter & 1] = (iter + 2 < n_stat) ? static_id(iter + 2) : (int)pending;
+    __syncthreads();
+    JAC_STAMP(7);
+    cur = nxt;
+    nxt_id = __builtin_amdgcn_readfirstlane(slot[iter & 1]);
+    ++iter;
   }
 }
 
@@ -1129,8 +1155,7 @@ __global__ __launch_bounds__(256, 2) void jacobi_fused_round_kernel(const double
                                                                     double* Jr_next, double* Ji_next, double* Dr_next,
                                                                     double* Di_next, double tol, const double* scal,
                                                                     unsigned long long* sweep_off, int max_sweeps, int cross_only,
-                                                                    int S, int ld, unsigned int* work_counter, int zch, int zw,
-                                                                    unsigned int* cu_table, unsigned int tag) {
+                                                                    int S, int ld, unsigned int* work_counter, int zch, int n_static) {
   __shared__ union U {
     JacTileSmem<NT, CPLX> t;
     JacUpdSmem<NT, CPLX> u;
@@ -1140,23 +1165,6 @@ __global__ __launch_bounds__(256, 2) void jacobi_fused_round_kernel(const double
 #ifdef XMCA_JAC_PROF
   if (threadIdx.x == 0 && blockIdx.x < JAC_PROF_WG) jac_prof[(int)blockIdx.x * JAC_PROF_IT * JAC_PROF_ST + 8] = (long long)__builtin_readcyclecounter();
 #endif
-  // The tile solves are the serial chain of the whole eigensolver and they are VALU/LDS-latency bound; a co-resident
-  // update workgroup (back-to-back f64 MFMA on the same SIMDs) slows their rotation steps 2.3x (s_memtime stamps on
-  // MI355X).  So a solver workgroup marks its CU, and an update workgroup that finds itself on a marked CU leaves
-  // before it claims any work (the counter hands its share to the others).  Placement is only read, never assumed:
-  // if the update workgroup happens to arrive first, both simply share the CU as before.
-  if (cu_table) {
-    const unsigned int key = (__builtin_amdgcn_s_getreg(6164 /* XCC_ID[3:0] */) << 8) | __builtin_amdgcn_s_getreg(14852 /* HW_ID[15:8]: SE, SH, CU */);
-    if ((int)blockIdx.x < S) {
-      if (threadIdx.x == 0) atomicMax(cu_table + key, 2u * tag + 1u);
-    } else {
-      if (threadIdx.x == 0) slot[0] = atomicMax(cu_table + key, 2u * tag) == 2u * tag + 1u;
-      __syncthreads();
-      const int leave = slot[0];
-      __syncthreads();
-      if (leave) return;
-    }
-  }
   if ((int)blockIdx.x < S) {
     jacobi_assemble_next_diag<NT, CPLX>(sm.t, sm.u, blockIdx.x, S, Gr_in, Gi_in, ld, Jr, Ji, Dr, Di);
 #ifdef XMCA_JAC_PROF
@@ -1173,7 +1181,7 @@ __global__ __launch_bounds__(256, 2) void jacobi_fused_round_kernel(const double
   return;
 #endif
   jacobi_persistent_update<NT, CPLX>(sm.u, slot, work_counter, Gr_in, Gi_in, Gr_out, Gi_out, Zr_in, Zi_in, Zr_out, Zi_out, Jr, Ji, Dr,
-                                     Di, S, ld, zch, zw);
+                                     Di, S, ld, zch, n_static, (int)blockIdx.x < S ? -1 : (int)blockIdx.x - S, (int)gridDim.x - S);
 }
 
 __global__ void jacobi_diag_kernel(const double* __restrict__ Gr, int npad, double* __restrict__ d) {
@@ -1223,7 +1231,6 @@ struct EvdWorkspace {
   DevBuf<unsigned long long> off;   // one accumulator per sweep (ring)
   DevBuf<int> perm;
   DevBuf<unsigned int> work;        // one work counter per round (fused round kernel)
-  DevBuf<unsigned int> cu_table;    // per-CU marks of the solver workgroups (fused round kernel)
   hipStream_t aux = nullptr;        // second stream: diagonal-tile solves of the NEXT round
   hipEvent_t ev_head[4] = {nullptr, nullptr, nullptr, nullptr}, ev_evd[4] = {nullptr, nullptr, nullptr, nullptr};
   ~EvdWorkspace() {
@@ -1322,9 +1329,8 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
   };
 
   // fused rounds: persistent workgroups (two per CU) pull items from one counter per round
-  static const int zw = [] { const char* e = std::getenv("XMCA_JAC_ZW"); return (e && e[0] == '2') ? 2 : 1; }();   // eigenvector tiles per work item: singles balance the tail better
-  const int zch2 = want_z ? (S + zw - 1) / zw : 0;
-  const int fused_items = n_off + S * zch2 + S;
+  const int zch2 = want_z ? S : 0;
+  const int fused_items = n_off + S * zch2;
   static const int resident_wgs = [] {
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
@@ -1332,10 +1338,12 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
     return 2 * cus;
   }();
   const int fused_grid = std::max(S, std::min(resident_wgs, S + fused_items));
-  static const bool exclusive_on = [] { const char* e = std::getenv("XMCA_JACOBI_EXCL"); return !(e && e[0] == '0'); }();
+  // static share of the work items per worker: by default the whole even split, the remainder is claimed (workgroups that leave their CU take none)
+  static const int static_pct = [] { const char* e = std::getenv("XMCA_JACOBI_STATIC"); const int v = e ? std::atoi(e) : 100; return std::min(std::max(v, 0), 100); }();
+  const int n_workers = fused_grid - S;
+  // eigenvector tiles handed out statically per worker (the G tiles always are)
+  const int n_static = n_workers <= 0 ? 0 : (int)((int64_t)S * zch2 * static_pct / 100 / n_workers);
   if (lookahead) {
-    ws.cu_table.ensure(4096);
-    XMCA_HIP(hipMemsetAsync(ws.cu_table.get(), 0, sizeof(unsigned int) * 4096, st));
     ws.work.ensure((size_t)max_sweeps * rounds);
     XMCA_HIP(hipMemsetAsync(ws.work.get(), 0, sizeof(unsigned int) * (size_t)max_sweeps * rounds, st));
   }
@@ -1360,9 +1368,24 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
                            CPLX ? ws.J[par][1].get() : nullptr, ws.D[par][0].get(), CPLX ? ws.D[par][1].get() : nullptr,
                            ws.J[par ^ 1][0].get(), CPLX ? ws.J[par ^ 1][1].get() : nullptr, ws.D[par ^ 1][0].get(),
                            CPLX ? ws.D[par ^ 1][1].get() : nullptr, tile_tol, ws.scal.get(), ws.off.get() + next_slot,
-                           inner_cap, is_cross((r + 1) % rounds) ? 1 : 0, S, npad, ws.work.get() + round_no, zch2, zw,
-                           exclusive_on ? ws.cu_table.get() : nullptr, (unsigned int)(round_no + 1));
+                           inner_cap, is_cross((r + 1) % rounds) ? 1 : 0, S, npad, ws.work.get() + round_no, zch2, n_static);
       }
+#ifdef XMCA_JAC_PROF
+      if (lookahead && round_no == 300) {   // stamps of a typical (cross-block) round in the middle of the solve
+        XMCA_HIP(hipStreamSynchronize(st));
+        std::vector<long long> h((size_t)JAC_PROF_WG * JAC_PROF_IT * JAC_PROF_ST);
+        XMCA_HIP(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(jac_prof), h.size() * sizeof(long long)));
+        if (FILE* f = std::fopen("gpurun_out/jac_prof.txt", "w")) {
+          for (int w = 0; w < JAC_PROF_WG; ++w)
+            for (int it = 0; it < JAC_PROF_IT; ++it) {
+              std::fprintf(f, "%d %d", w, it);
+              for (int k = 0; k < JAC_PROF_ST; ++k) std::fprintf(f, " %lld", h[((size_t)w * JAC_PROF_IT + it) * JAC_PROF_ST + k]);
+              std::fprintf(f, "\n");
+            }
+          std::fclose(f);
+        }
+      }
+#endif
       cur ^= 1;
     }
     XMCA_HIP(hipGetLastError());
@@ -1388,21 +1411,6 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
     if (!(left >= tol) || !std::isfinite(left)) { off = left; break; }
   }
   XMCA_CHECK(std::isfinite(off), XMCA_ERR_NUMERIC, "SVD failed. NaN entries may be the problem.");
-#ifdef XMCA_JAC_PROF
-  if (lookahead) {   // stamps of the last round
-    std::vector<long long> h((size_t)JAC_PROF_WG * JAC_PROF_IT * JAC_PROF_ST);
-    XMCA_HIP(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(jac_prof), h.size() * sizeof(long long)));
-    if (FILE* f = std::fopen("gpurun_out/jac_prof.txt", "w")) {
-      for (int w = 0; w < JAC_PROF_WG; ++w)
-        for (int it = 0; it < JAC_PROF_IT; ++it) {
-          std::fprintf(f, "%d %d", w, it);
-          for (int k = 0; k < JAC_PROF_ST; ++k) std::fprintf(f, " %lld", h[((size_t)w * JAC_PROF_IT + it) * JAC_PROF_ST + k]);
-          std::fprintf(f, "\n");
-        }
-      std::fclose(f);
-    }
-  }
-#endif
 
   // eigenvalues = diagonal; sort descending on the host, drop the padding (= the most negative entries)
   hipLaunchKernelGGL(jacobi_diag_kernel, dim3(ceil_div(npad, 256)), dim3(256), 0, st, ws.G[cur][0].get(), npad, ws.diag.get());
