@@ -368,19 +368,6 @@ __device__ __forceinline__ void jacobi_tile_evd_body(JacTileSmem<NT, CPLX>& sm, 
   }
 }
 
-// Which tiles of round r must exist before the diagonal tiles of round r+1 can be solved ("lookahead head"):
-// the new pair slot P' is made of one half of two different old slots (A, B); its off-diagonal quarter comes from
-// the updated tile (A, B).  With the tournament of jacobi_dest_block these are (0,1), (P,P+2) and (S-2,S-1).
-__host__ __device__ inline bool jacobi_is_next_diag(int P, int Q, int S) {
-  if (S <= 2) return true;
-  return (P == 0 && Q == 1) || (Q == P + 2) || (P == S - 2 && Q == S - 1);
-}
-__host__ __device__ inline void jacobi_next_diag_pair(int Pn, int S, int& A, int& B) {
-  if (S <= 2 || Pn == 0) { A = 0; B = 1; return; }
-  if (Pn == S - 1) { A = S - 2; B = S - 1; return; }
-  A = Pn - 1; B = Pn + 1;
-}
-
 #ifndef XMCA_JAC_ZW
 #define XMCA_JAC_ZW 4
 #endif
@@ -391,12 +378,12 @@ constexpr int JAC_ZW = XMCA_JAC_ZW;   // eigenvector tiles (NT x NT) handled per
 #define JAC_STORE(ptr, val) (*(ptr) = (val))
 #endif
 
-// One round of the two-sided update:  G'[P,Q] = J_P^H G[P,Q] J_Q (upper tiles + mirrored write),
-// Z'[P,c] = J_P^H Z[P,c], both written to the slots of the next round.
-//   MODE 0: all tiles.   MODE 1: diagonal tiles + lookahead head.   MODE 2: everything else.
+// One round of the two-sided update, one workgroup per tile (the plain form, used for problems of one or two pair
+// slots; the fused rounds below use jacobi_persistent_update):  G'[P,Q] = J_P^H G[P,Q] J_Q (upper tiles + mirrored
+// write), Z'[P,c] = J_P^H Z[P,c], both written to the slots of the next round.
 // Two LDS buffers (J and tile) so that two workgroups fit a CU; results are staged through LDS and leave as
 // full 256-byte row segments (also the mirrored, transposed copy).
-template <int NT, bool CPLX, int MODE>
+template <int NT, bool CPLX>
 __device__ __forceinline__ void jacobi_update_body(JacUpdSmem<NT, CPLX>& sm, const int block_id, const double* __restrict__ Gr_in,
                                                    const double* __restrict__ Gi_in, double* __restrict__ Gr_out,
                                                    double* __restrict__ Gi_out, const double* __restrict__ Zr_in,
@@ -420,34 +407,20 @@ __device__ __forceinline__ void jacobi_update_body(JacUpdSmem<NT, CPLX>& sm, con
   int kind, P, Q;   // kind 0: diagonal tile, 1: off-diagonal G tile, 2: Z chunk
   {
     int id = block_id;
-    if (MODE == 1) {
-      if (id < S) { kind = 0; P = Q = id; }
-      else {
+    if (id < S) { kind = 0; P = Q = id; }
+    else {
+      id -= S;
+      if (id < n_off) {
         kind = 1;
-        jacobi_next_diag_pair(id - S, S, P, Q);
-        if (S <= 2 && id - S > 0) return;               // S == 2: both new slots need the same tile
-      }
-    } else {
-      int base = 0;
-      if (MODE == 0) {
-        if (id < S) { kind = 0; P = Q = id; }
-        base = S;
-      }
-      if (MODE == 2 || id >= base) {
-        id -= base;
-        if (id < n_off) {
-          kind = 1;
-          P = 0;
-          int rem = id;
-          while (rem >= S - 1 - P) { rem -= S - 1 - P; ++P; }
-          Q = P + 1 + rem;
-          if (MODE == 2 && jacobi_is_next_diag(P, Q, S)) return;
-        } else {
-          id -= n_off;
-          kind = 2;
-          P = id / zchunks;
-          Q = (id % zchunks) * JAC_ZW;
-        }
+        P = 0;
+        int rem = id;
+        while (rem >= S - 1 - P) { rem -= S - 1 - P; ++P; }
+        Q = P + 1 + rem;
+      } else {
+        id -= n_off;
+        kind = 2;
+        P = id / zchunks;
+        Q = (id % zchunks) * JAC_ZW;
       }
     }
   }
@@ -793,17 +766,17 @@ __global__ __launch_bounds__(256, 2) void jacobi_tile_evd_kernel(const double* G
   jacobi_tile_evd_body<NT, CPLX>(sm, blockIdx.x, Gr, Gi, ld, Jr, Ji, Dr, Di, tol, scal, sweep_off, max_sweeps, cross_only != 0);
 }
 
-template <int NT, bool CPLX, int MODE>
+template <int NT, bool CPLX>
 __global__ __launch_bounds__(256, 2) void jacobi_update_kernel(const double* Gr_in, const double* Gi_in, double* Gr_out,
                                                                double* Gi_out, const double* Zr_in, const double* Zi_in,
                                                                double* Zr_out, double* Zi_out, const double* Jr, const double* Ji,
                                                                const double* Dr, const double* Di, int S, int ld) {
   __shared__ JacUpdSmem<NT, CPLX> sm;
-  jacobi_update_body<NT, CPLX, MODE>(sm, blockIdx.x, Gr_in, Gi_in, Gr_out, Gi_out, Zr_in, Zi_in, Zr_out, Zi_out, Jr, Ji, Dr, Di, S,
+  jacobi_update_body<NT, CPLX>(sm, blockIdx.x, Gr_in, Gi_in, Gr_out, Gi_out, Zr_in, Zi_in, Zr_out, Zi_out, Jr, Ji, Dr, Di, S,
                                      ld, false);
 }
 
-// ---- persistent, software-pipelined form of the MODE 0 update (fused round kernel) --------------------------------
+// ---- persistent, software-pipelined form of the update (fused round kernel) --------------------------------
 // Work items of a round, taken from an atomic counter (heaviest first):
 //   kind 1: G tile (P,Q), P < Q          J_P^H G[P,Q] J_Q      loads J_P, T, J_Q   - two tile products
 //   kind 2: eigenvector tiles (P, Q..Q+1) J_P^H Z[P,Q..]       loads J_P, T0, T1   - two tile products
@@ -1231,26 +1204,6 @@ struct EvdWorkspace {
   DevBuf<unsigned long long> off;   // one accumulator per sweep (ring)
   DevBuf<int> perm;
   DevBuf<unsigned int> work;        // one work counter per round (fused round kernel)
-  hipStream_t aux = nullptr;        // second stream: diagonal-tile solves of the NEXT round
-  hipEvent_t ev_head[4] = {nullptr, nullptr, nullptr, nullptr}, ev_evd[4] = {nullptr, nullptr, nullptr, nullptr};
-  ~EvdWorkspace() {
-    for (int i = 0; i < 4; ++i) {
-      if (ev_head[i]) (void)hipEventDestroy(ev_head[i]);
-      if (ev_evd[i]) (void)hipEventDestroy(ev_evd[i]);
-    }
-    if (aux) (void)hipStreamDestroy(aux);
-  }
-  void init_streams() {
-    if (aux) return;
-    // highest priority: the 46-odd workgroups of a diagonal-tile solve must not queue behind the ~3000 of the update
-    int lo = 0, hi = 0;
-    XMCA_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    XMCA_HIP(hipStreamCreateWithPriority(&aux, hipStreamNonBlocking, hi));
-    for (int i = 0; i < 4; ++i) {
-      XMCA_HIP(hipEventCreateWithFlags(&ev_head[i], hipEventDisableTiming));
-      XMCA_HIP(hipEventCreateWithFlags(&ev_evd[i], hipEventDisableTiming));
-    }
-  }
 };
 
 struct EvdInfo {
@@ -1319,9 +1272,8 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
                        ws.D[par][0].get(), CPLX ? ws.D[par][1].get() : nullptr, tile_tol, ws.scal.get(),
                        ws.off.get() + sweep_slot, S == 1 ? 60 : inner_cap, is_cross(round_in_sweep) ? 1 : 0);
   };
-  auto update = [&](auto mode_tag, hipStream_t s, int par, int grid) {
-    constexpr int MODE = decltype(mode_tag)::value;
-    hipLaunchKernelGGL((jacobi_update_kernel<NT, CPLX, MODE>), dim3(grid), dim3(256), 0, s, ws.G[cur][0].get(),
+  auto update = [&](hipStream_t s, int par, int grid) {
+    hipLaunchKernelGGL((jacobi_update_kernel<NT, CPLX>), dim3(grid), dim3(256), 0, s, ws.G[cur][0].get(),
                        CPLX ? ws.G[cur][1].get() : nullptr, ws.G[cur ^ 1][0].get(), CPLX ? ws.G[cur ^ 1][1].get() : nullptr,
                        ws.Z[cur][0].get(), CPLX ? ws.Z[cur][1].get() : nullptr, ws.Z[cur ^ 1][0].get(),
                        CPLX ? ws.Z[cur ^ 1][1].get() : nullptr, ws.J[par][0].get(), CPLX ? ws.J[par][1].get() : nullptr,
@@ -1338,7 +1290,7 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
     return 2 * cus;
   }();
   const int fused_grid = std::max(S, std::min(resident_wgs, S + fused_items));
-  // static share of the work items per worker: by default the whole even split, the remainder is claimed (workgroups that leave their CU take none)
+  // XMCA_JACOBI_STATIC: percentage of an even split of the eigenvector tiles that is handed out statically
   static const int static_pct = [] { const char* e = std::getenv("XMCA_JACOBI_STATIC"); const int v = e ? std::atoi(e) : 100; return std::min(std::max(v, 0), 100); }();
   const int n_workers = fused_grid - S;
   // eigenvector tiles handed out statically per worker (the G tiles always are)
@@ -1357,7 +1309,7 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
       const int par = (int)(round_no & 1);
       if (!lookahead) {
         evd(st, cur, par, sweep, r);
-        update(std::integral_constant<int, 0>{}, st, par, S + n_off + S * zchunks);
+        update(st, par, S + n_off + S * zchunks);
       } else {
         // ONE launch: tile solves of round r+1 (assembled from this round's G, J, D) + the whole update of round r
         const int next_slot = (r == rounds - 1) ? sweep + 1 : sweep;
