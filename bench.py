@@ -153,8 +153,13 @@ def main():
         t2 = time.perf_counter()
         m.rotate(args.n_rot, args.power)
         t3 = time.perf_counter()
+        pcs = m.pcs(args.n_rot)                     # X V on the resident field (device GEMM)
+        t4 = time.perf_counter()
+        host_pcs = X @ m._V['left'][:, :args.n_rot]   # the reference's host product, for scale
+        t5 = time.perf_counter()
         extra["e2e_ms"] = {"ctor": 1e3 * (t1 - t0), "solve": 1e3 * (t2 - t1), "rotate": 1e3 * (t3 - t2),
-                           "upload_only": 1e3 * upload_s}
+                           "upload_only": 1e3 * upload_s, "pcs_device": 1e3 * (t4 - t3), "pcs_host_product_only": 1e3 * (t5 - t4)}
+        del pcs, host_pcs
         extra["varimax_iterations"] = m._varimax_iterations
 
     # ---- sharded rule_n (one all_gather of the spectra), bounded size ----

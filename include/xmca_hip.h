@@ -71,6 +71,15 @@ int xmca_get_singular_values(xmca_handle* h, double* out, int64_t n);
 /* MCA._V[key] (array.py:584), transposed: out[m * N + n] = V[n][m] for m < n_modes; complex interleaved when
  * the model is complex.  dtype selects float32 / float64 components. */
 int xmca_get_vectors(xmca_handle* h, int side, void* out, int64_t n_modes, int dtype);
+
+/* PC projection of MCA._get_U (xmca/array.py:648-674, the product `fields[k] @ V[k]`): U = X~ V with X~ the field of
+ * `side` as solve() saw it - still resident on the device; the analytic signal X + i Ht X when complexify was
+ * requested (the imaginary field plane is not needed: U = W + i Ht W with W = X V).
+ *   V      N x m row-major, float64 (is_complex = 0) or interleaved complex128 (is_complex = 1), host memory
+ *   U_out  T x m row-major float64, interleaved complex128 when *out_is_complex = 1 (model or V complex)
+ * The scaling by 1/sqrt(sigma) and the rotation (array.py:391-393) stay with the caller (m x m work). */
+int xmca_project(xmca_handle* h, int side, const void* V, int64_t N, int64_t m, int is_complex, void* U_out,
+                 int* out_is_complex);
 int xmca_is_complex(xmca_handle* h);
 /* Diagnostics of the last solve: for each of the up to three eigen-decompositions (left Gram, right Gram, kernel):
  * info[3*i + 0] = outer sweeps, info[3*i + 1] = tile size, info[3*i + 2] = pair slots.  n <= 9. */

@@ -111,6 +111,8 @@ def test_getters_on_injected_state(cplx, rot):
         m._rotation_matrix, m._correlation_matrix = ro["R"], ro["Phi"]
         m._analysis.update({'is_rotated': True, 'n_rot': rot[0], 'power': rot[1]})
     n = rot[0] if rot else 5
+    # the product X @ V of _get_U runs on the device (tests/test_gpu_mca.py); here only the host algebra around it
+    m._project_on_device = lambda V: {k: f @ V[k] for k, f in zip(m._keys, om.fields)}
     eofs, pcs = m.eofs(n), m.pcs(n)
     X = om.fields
     for i, k in enumerate(m._keys):

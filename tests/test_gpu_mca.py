@@ -263,3 +263,44 @@ def test_bootstrapping_runs():
     single.solve()
     with pytest.raises(ValueError):
         single.bootstrapping(2, on_left=False, on_right=True)
+
+
+# ----------------------------------------------------------------------------------------------
+# PC projection on the device (`_get_U`, array.py:648-674)
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,cplx,analytic", [("wide_both", False, "1"), ("wide_both", True, "1"), ("wide_both", True, "0"),
+                                                ("wide_both_f32", True, "1"), ("small_both", True, "1"), ("unit_left", False, "1")])
+def test_pcs_projection_matches_host_formula(name, cplx, analytic, monkeypatch):
+    """pcs() = X~ V / sqrt(sigma) (array.py:391): the product runs on the fields resident on the device - real fields,
+    the implicit analytic signal of the subspace path (U = W + i Ht W), stored complex planes (general path), f32."""
+    monkeypatch.setenv("XMCA_ANALYTIC", analytic)
+    fields = make_input(name)
+    m = MCA(*fields)
+    m.solve(complexify=cplx)
+    k = 12
+    pcs = m.pcs(k)
+    X = m._get_X()                                           # host copy (scipy.signal.hilbert when complex)
+    for key in m._keys:
+        ref = X[key] @ m._V[key][:, :k] / np.sqrt(m._singular_values[:k])
+        tol = 2e-4 if X[key].real.dtype == np.float32 else 1e-9
+        assert pcs[key].shape == ref.shape
+        assert _rel(pcs[key], ref) < tol
+
+
+def test_pcs_projection_after_the_handle_was_used_elsewhere():
+    """another model's solve() and rule_n() overwrite the resident fields: the projection uploads its own again."""
+    a = MCA(*make_input("wide_both"))
+    a.solve(complexify=True)
+    a.rotate(6, 2)
+    first = a.pcs(6)
+    b = MCA(*make_input("small_both"))
+    b.solve()
+    b.rule_n(2, seed=3)
+    again = a.pcs(6)
+    for key in a._keys:
+        assert _rel(again[key], first[key]) < 1e-12
+    X = a._get_X()
+    R = a.rotation_matrix(inverse_transpose=True)
+    for key in a._keys:
+        ref = ((X[key] @ a._V[key][:, :6] / np.sqrt(a._singular_values[:6])) @ R)[:, a._var_idx]
+        assert _rel(first[key], ref) < 1e-9

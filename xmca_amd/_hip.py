@@ -35,6 +35,7 @@ SIGNATURES = {
     "xmca_solve": (_c_int, [_vp, _c_int, _c_i64, ctypes.POINTER(_c_i64)]),
     "xmca_get_singular_values": (_c_int, [_vp, _vp, _c_i64]),
     "xmca_get_vectors": (_c_int, [_vp, _c_int, _vp, _c_i64, _c_int]),
+    "xmca_project": (_c_int, [_vp, _c_int, _vp, _c_i64, _c_i64, _c_int, _vp, ctypes.POINTER(_c_int)]),
     "xmca_is_complex": (_c_int, [_vp]),
     "xmca_get_solve_info": (_c_int, [_vp, _vp, _c_int]),
     "xmca_rotate_loadings": (_c_int, [_vp, _vp, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_dbl, _c_int, _c_int,
@@ -165,6 +166,7 @@ class Handle:
     # ---- fields -------------------------------------------------------------------------------
     def set_field(self, side, field):
         """field: T x N numpy array (real or complex, float32/float64 based)."""
+        self.fields_owner = None            # whoever uploads claims the resident fields afterwards (MCA._upload_fields)
         field = np.asarray(field)
         if field.ndim != 2:
             raise ValueError("field must be 2-D (time x space)")
@@ -215,6 +217,20 @@ class Handle:
         self._check(self._lib.xmca_get_vectors(self._h, side, _ptr(out), n_modes, code))
         return out
 
+    def project(self, side, V, T):
+        """U = X~ V (T x m) on the resident field of `side` (the analytic signal when the model is complex);
+        float64 / complex128.  MCA._get_U's `fields[k] @ V[k]` (array.py:391)."""
+        V = np.asarray(V)
+        cplx = np.iscomplexobj(V)
+        Vd = np.ascontiguousarray(V, dtype=np.complex128 if cplx else np.float64)
+        N, m = Vd.shape
+        out = np.empty((T, m), dtype=np.complex128)          # large enough for either result type
+        out_cplx = _c_int(0)
+        self._check(self._lib.xmca_project(self._h, side, _ptr(Vd), N, m, int(cplx), _ptr(out), ctypes.byref(out_cplx)))
+        if out_cplx.value:
+            return out
+        return out.view(np.float64).reshape(-1)[:T * m].reshape(T, m).copy()
+
     # ---- rotation -----------------------------------------------------------------------------
     def rotate_loadings(self, L, n_left, power=1, tol=1e-8, max_iter=1000, varimax_only=False, want_B=False):
         L = np.asarray(L)
@@ -238,6 +254,7 @@ class Handle:
     # ---- rule N -------------------------------------------------------------------------------
     def rule_n(self, T, Nx, Ny, n_fields, complexify, rotated, p, power, tol, run_begin, run_end, seed, dtype, n_out):
         n = run_end - run_begin
+        self.fields_owner = None            # the surrogates overwrite the resident fields
         spectra = np.zeros((max(n, 0), n_out), dtype=np.float64)
         kept = np.zeros(max(n, 0), dtype=np.int32)
         ht = hilbert_imag_column(T) if complexify else None

@@ -45,6 +45,8 @@ class MCA:
             self._keys.pop()
         self._fields_store = {}
         self._pending_hilbert = False
+        self._device_hilbert = False
+        self._upload_serial = 0
         self._shape = {}
         self._field_names = {}
         self._field_means = {}
@@ -293,22 +295,19 @@ class MCA:
         self._analysis['theta_period'] = period
 
         dev = self._device()
-        n_obs = self._n_observations['left']
         if complexify and extend:
             self._fields = self._complexify(self._fields)           # host path (nonlinear extension)
-            for side, k in enumerate(self._keys):
-                dev.set_field(side, _device_ready(self._fields_store[k]))
+            self._device_hilbert = False
         else:
             real = {k: self._fields[k].real if np.iscomplexobj(self._fields_store[k]) else self._fields_store[k]
                     for k in self._keys}
-            for side, k in enumerate(self._keys):
-                dev.set_field(side, _device_ready(real[k]))
+            self._device_hilbert = bool(complexify)                  # X_im = Ht X on the device
             if complexify:
-                dev.complexify(n_obs)                                # X_im = Ht X on the device
                 self._fields_store = real
                 self._pending_hilbert = True                         # host copy of the analytic signal: on first use
             else:
                 self._fields = real
+        self._upload_fields(dev)
 
         try:
             rank = dev.solve(len(self._keys))
@@ -379,17 +378,42 @@ class MCA:
             V[k] = V[k][:, keep]
         return V
 
+    def _upload_fields(self, dev):
+        """Makes the fields solve() works on resident on the device and records this model as their owner."""
+        store = self._fields_store
+        for side, k in enumerate(self._keys):
+            dev.set_field(side, _device_ready(store[k]))
+        if self._device_hilbert and not any(np.iscomplexobj(f) for f in store.values()):
+            dev.complexify(self._n_observations['left'])        # (a materialised host analytic signal goes up as it is)
+        dev.fields_owner = (id(self), self._upload_serial)
+
+    def _project_on_device(self, V):
+        """fields[k] @ V[k] of `_get_U` (array.py:391) as a device GEMM over the resident fields."""
+        dev = self._device()
+        if getattr(dev, 'fields_owner', None) != (id(self), self._upload_serial):
+            self._upload_serial += 1          # another model / rule_n used the handle in between: upload again
+            self._upload_fields(dev)
+        T = self._n_observations['left']
+        return {k: dev.project(side, V[k], T) for side, k in enumerate(self._keys)}
+
     def _get_U(self, n=None, rotated=True):
-        max_mode = self._max_mode(n, rotated)
         keep = self._get_slice(n)
-        fields = self._get_X()
+        mix = rotated and self._analysis['is_rotated']
+        if mix:
+            max_mode = self._max_mode(n, rotated)
+        else:
+            # the reference multiplies by the identity rotation matrix over all `rank` modes here (array.py:393); only
+            # the kept modes are projected instead - same numbers, no T x N x rank product for pcs(10), and the
+            # null modes (sigma = 0 exactly on the device) cannot leak 0 * inf into the kept columns
+            max_mode = keep.stop if keep.stop is not None else self._analysis['rank']
         V = self._get_V(max_mode, rotated=False)
         sqrt_svals = np.sqrt(self._get_svals(max_mode))
-        R = self.rotation_matrix(inverse_transpose=True)
+        XV = self._project_on_device(V)
         U = {}
         for k in self._keys:
-            U[k] = fields[k] @ V[k] / sqrt_svals
-            if rotated:
+            U[k] = XV[k].astype(np.result_type(V[k].dtype, self._fields_store[k].dtype), copy=False) / sqrt_svals
+            if mix:
+                R = self.rotation_matrix(inverse_transpose=True)
                 U[k] = (U[k] @ R)[:, self._var_idx]
             U[k] = U[k][:, keep]
         return U

@@ -171,6 +171,77 @@ void get_vectors_impl(xmca_handle* h, int side, void* out, int64_t m) {
   XMCA_HIP(hipStreamSynchronize(h->st));
 }
 
+// U = X~ V on the resident field of `side` (see xmca_project)
+template <typename TI>
+void project_impl(xmca_handle* h, int side, const void* V, int64_t N, int64_t m, bool v_cplx, void* U_out, int* out_cplx) {
+  FieldData<TI>& f = fields_of<TI>(h)[side];
+  XMCA_CHECK(f.N == N, XMCA_ERR_INVALID, "project: V has " + std::to_string(N) + " rows, the field has " + std::to_string(f.N) + " columns");
+  const int64_t T = f.T;
+  const bool analytic = !f.has_im && h->hilbert_pending;       // imaginary plane implicit: X~ = X + i Ht X
+  const bool f_cplx = f.has_im || analytic, cplx = f_cplx || v_cplx;
+  // V -> planes in the field's element type (N x m, ld = m)
+  const size_t nv = (size_t)N * m;
+  DevBuf<double> vh;
+  DevBuf<TI> vr, vi;
+  XMCA_HIP(hipMemcpyAsync(vh.ensure(nv * (v_cplx ? 2 : 1)), V, sizeof(double) * nv * (v_cplx ? 2 : 1), hipMemcpyHostToDevice, h->st));
+  if (v_cplx)
+    hipLaunchKernelGGL((split_complex_kernel<double, TI>), ew_grid((int64_t)nv), dim3(EW_BLOCK), 0, h->st, vh.get(), vr.ensure(nv), vi.ensure(nv), (int64_t)nv);
+  else
+    hipLaunchKernelGGL((convert_kernel<double, TI>), ew_grid((int64_t)nv), dim3(EW_BLOCK), 0, h->st, vh.get(), vr.ensure(nv), (int64_t)nv);
+  XMCA_HIP(hipGetLastError());
+  h->tm.begin("project");
+  DevBuf<double> wr, wi, ur, ui;
+  const size_t nu = (size_t)T * m;
+  wr.ensure(nu);
+  if (cplx) wi.ensure(nu);
+  // W = X V on the stored planes (complex x complex through cgemm; a missing plane is a zero plane)
+  if (f.has_im || v_cplx) {
+    if (f.has_im && v_cplx) {
+      cgemm<TI>(h->st, h->gws, f.r(), f.i(), f.N, true, false, vr.get(), vi.get(), m, true, false, wr.get(), wi.get(), m, (int)T,
+                (int)m, (int)N, 1.0, nullptr, nullptr, false);
+    } else if (f.has_im) {      // complex field, real V
+      GemmOpts o;
+      gemm<TI, double>(h->st, h->gws, f.r(), f.N, vr.get(), m, wr.get(), m, (int)T, (int)m, (int)N, o);
+      gemm<TI, double>(h->st, h->gws, f.i(), f.N, vr.get(), m, wi.get(), m, (int)T, (int)m, (int)N, o);
+    } else {                    // real field plane, complex V
+      GemmOpts o;
+      gemm<TI, double>(h->st, h->gws, f.r(), f.N, vr.get(), m, wr.get(), m, (int)T, (int)m, (int)N, o);
+      gemm<TI, double>(h->st, h->gws, f.r(), f.N, vi.get(), m, wi.get(), m, (int)T, (int)m, (int)N, o);
+    }
+  } else {
+    GemmOpts o;
+    gemm<TI, double>(h->st, h->gws, f.r(), f.N, vr.get(), m, wr.get(), m, (int)T, (int)m, (int)N, o);
+    if (cplx) XMCA_HIP(hipMemsetAsync(wi.get(), 0, sizeof(double) * nu, h->st));
+  }
+  const double* out_r = wr.get();
+  const double* out_i = cplx ? wi.get() : nullptr;
+  DevBuf<double> ht;
+  if (analytic) {
+    // U = W + i Ht W:  Ur = Wr - Ht Wi,  Ui = Wi + Ht Wr
+    XMCA_CHECK((int64_t)h->hilbert_col.size() == T, XMCA_ERR_STATE, "project: the Hilbert column of the model is missing");
+    build_hilbert<double>(h, h->hilbert_col.data(), T, ht);
+    XMCA_HIP(hipMemcpyAsync(ur.ensure(nu), wr.get(), sizeof(double) * nu, hipMemcpyDeviceToDevice, h->st));
+    XMCA_HIP(hipMemcpyAsync(ui.ensure(nu), wi.get(), sizeof(double) * nu, hipMemcpyDeviceToDevice, h->st));
+    GemmOpts o;
+    o.beta = 1.0;
+    o.alpha = -1.0;
+    gemm<double, double>(h->st, h->gws, ht.get(), T, wi.get(), m, ur.get(), m, (int)T, (int)m, (int)T, o);
+    o.alpha = 1.0;
+    gemm<double, double>(h->st, h->gws, ht.get(), T, wr.get(), m, ui.get(), m, (int)T, (int)m, (int)T, o);
+    out_r = ur.get();
+    out_i = ui.get();
+  }
+  h->tm.end();
+  DevBuf<double> packed;
+  const size_t n_out = nu * (cplx ? 2 : 1);
+  hipLaunchKernelGGL((pack_rows_kernel<double>), ew_grid((int64_t)nu), dim3(EW_BLOCK), 0, h->st, out_r, out_i, m, (int)T, (int)m,
+                     packed.ensure(n_out), 0);
+  XMCA_HIP(hipGetLastError());
+  XMCA_HIP(hipMemcpyAsync(U_out, packed.get(), sizeof(double) * n_out, hipMemcpyDeviceToHost, h->st));
+  XMCA_HIP(hipStreamSynchronize(h->st));
+  *out_cplx = cplx ? 1 : 0;
+}
+
 void fill_rot_outputs(const RotateResult& rr, bool cplx, double* R_out, double* Phi_out, double* nl, double* nr, int* iters) {
   const int p = rr.p;
   if (iters) *iters = rr.iters;
@@ -377,6 +448,17 @@ int xmca_get_vectors(xmca_handle* h, int side, void* out, int64_t n_modes, int d
     if (dtype == XMCA_F32) get_vectors_impl<float>(h, side, out, n_modes);
     else get_vectors_impl<double>(h, side, out, n_modes);
   }
+  API_END(h)
+}
+
+int xmca_project(xmca_handle* h, int side, const void* V, int64_t N, int64_t m, int is_complex, void* U_out,
+                 int* out_is_complex) {
+  API_BEGIN(h)
+  XMCA_CHECK(side == 0 || side == 1, XMCA_ERR_INVALID, "project: side must be 0 or 1");
+  XMCA_CHECK(h->field_set[side], XMCA_ERR_STATE, "project: no field resident for this side");
+  XMCA_CHECK(V && U_out && out_is_complex && N >= 1 && m >= 1, XMCA_ERR_INVALID, "project: need an N x m matrix of vectors");
+  if (h->dtype == XMCA_F32) project_impl<float>(h, side, V, N, m, is_complex != 0, U_out, out_is_complex);
+  else project_impl<double>(h, side, V, N, m, is_complex != 0, U_out, out_is_complex);
   API_END(h)
 }
 
