@@ -140,7 +140,9 @@ class MCA:
             self._field_stds[k] = f.std(axis=0)
 
     def _center(self, data):
-        return {k: remove_mean(f) for k, f in data.items()}
+        # time-major contiguous rows for the device upload (boolean column selection leaves a column-major layout; the
+        # means above were taken on it, exactly like the reference, so the values are bit-identical)
+        return {k: np.ascontiguousarray(remove_mean(f)) for k, f in data.items()}
 
     def _get_method_id(self):
         return 'mca' if self._analysis['is_bivariate'] else 'pca'
