@@ -192,21 +192,23 @@ __device__ __forceinline__ void jacobi_tile_evd_body(JacTileSmem<NT, CPLX>& sm, 
   // full mode: round-robin tournament over all NT indices (NT-1 steps).  cross mode: only the pairs (p, q) with p in
   // the first and q in the second half-block (NT/2 steps of cyclic shifts): the pairs inside a half-block have been
   // rotated when that half-block was last swept in full mode and need it only once per outer sweep.
-  auto pair_of = [cross_only](int k, int step, int& p, int& q) {
-    if (cross_only) {
-      p = k;
-      int j = k + step;
-      if (j >= H) j -= H;
-      q = H + j;
-      return;
-    }
-    int a, b;
-    if (k == 0) { a = NT - 1; b = step; }
-    else { a = step + k; if (a >= NT - 1) a -= NT - 1; b = step - k; if (b < 0) b += NT - 1; }
-    p = min(a, b); q = max(a, b);
-  };
-  const int n_steps = cross_only ? H : NT - 1;
   __builtin_amdgcn_s_setprio(3);   // latency-bound: when sharing a CU with MFMA-bound update workgroups, issue first
+  // The sweep is compiled twice: in cross mode (all rounds but the first of an outer sweep) p = k is fixed, so every
+  // row / column base of a thread is loop invariant and the step loses a third of its (integer) instructions.
+  auto run_sweeps = [&](auto cross_tag) {
+  constexpr bool CROSS = decltype(cross_tag)::value;
+  auto pair_of = [](int k, int step, int& p, int& q) {
+    if constexpr (CROSS) {
+      p = k;
+      q = H + ((k + step) & (H - 1));
+    } else {
+      int a, b;
+      if (k == 0) { a = NT - 1; b = step; }
+      else { a = step + k; if (a >= NT - 1) a -= NT - 1; b = step - k; if (b < 0) b += NT - 1; }
+      p = min(a, b); q = max(a, b);
+    }
+  };
+  const int n_steps = CROSS ? H : NT - 1;
   // One barrier per step.  Every wave computes all H rotations itself (lane l holds the rotation of pair l % H, which
   // is also this thread's column pair k2), so there is no "one wave computes, everybody waits" phase; the rotations of
   // the row pairs k1 come from the lanes that hold them.  The V update of a step does not feed the next rotation
@@ -355,6 +357,10 @@ __device__ __forceinline__ void jacobi_tile_evd_body(JacTileSmem<NT, CPLX>& sm, 
     }
     __syncthreads();
   }
+
+  };
+  if (cross_only) run_sweeps(std::true_type{});
+  else run_sweeps(std::false_type{});
 
 #ifdef XMCA_JAC_PROF
   if (PRELOADED && tid == 0) jac_prof[((int)blockIdx.x * JAC_PROF_IT) * JAC_PROF_ST + 6] = (long long)__builtin_readcyclecounter();
