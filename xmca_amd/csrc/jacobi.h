@@ -1126,8 +1126,16 @@ __device__ __forceinline__ void jacobi_persistent_update(JacUpdSmem<NT, CPLX>& s
 // One round = ONE launch of at most two workgroups per CU.  The first S workgroups assemble and sweep the diagonal
 // tiles of round r+1 (from G, J, D of round r: jacobi_assemble_next_diag); every workgroup (those S too, once they
 // are done) then pulls update items of round r from the work counter until none is left.
+// workgroups per CU of the fused round kernel: the 64 x 64 real tiles need 66 KB of LDS (two fit), the 32 x 32 complex
+// ones 34 KB (XMCA_JAC_WGS32 of them, registers permitting)
+#ifndef XMCA_JAC_WGS32
+#define XMCA_JAC_WGS32 4
+#endif
+template <int NT>
+constexpr int jacobi_fused_wgs_per_cu() { return NT >= 64 ? 2 : XMCA_JAC_WGS32; }
+
 template <int NT, bool CPLX>
-__global__ __launch_bounds__(256, 2) void jacobi_fused_round_kernel(const double* Gr_in, const double* Gi_in, double* Gr_out,
+__global__ __launch_bounds__(256, jacobi_fused_wgs_per_cu<NT>()) void jacobi_fused_round_kernel(const double* Gr_in, const double* Gi_in, double* Gr_out,
                                                                     double* Gi_out, const double* Zr_in, const double* Zi_in,
                                                                     double* Zr_out, double* Zi_out, const double* Jr,
                                                                     const double* Ji, const double* Dr, const double* Di,
@@ -1293,7 +1301,7 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    return 2 * cus;
+    return jacobi_fused_wgs_per_cu<NT>() * cus;
   }();
   const int fused_grid = std::max(S, std::min(resident_wgs, S + fused_items));
   // XMCA_JACOBI_STATIC: percentage of an even split of the eigenvector tiles that is handed out statically
