@@ -171,17 +171,22 @@ class Solver {
     std::vector<double> lam;
   };
 
+  // G = X X^H (T x T, both triangles):  Gr = Xr Xr^T + Xi Xi^T ;  Gi = Xi Xr^T - Xr Xi^T
+  void gram(const FieldData<TI>& f, bool cplx, CPlanes& G) {
+    const int T = (int)f.T;
+    G.ensure((size_t)T * T, cplx);
+    tm.begin("gram");
+    cgemm<TI>(st, gws, f.r(), f.i(), f.N, true, false, f.r(), f.i(), f.N, false, true, G.r(), G.i(cplx), T, T, T, (int)f.N, 1.0,
+              nullptr, nullptr, true);
+    tm.end();
+  }
+
   void reduce_field(const FieldData<TI>& f, bool cplx, Reduced& R, CPlanes& G, EvdInfo* info, bool want_vectors = true) {
     const int T = (int)f.T;
     R.reduced = f.N > f.T;
     R.r = (int)std::min(f.T, f.N);
     if (!R.reduced) return;
-    G.ensure((size_t)T * T, cplx);
-    tm.begin("gram");
-    // G = X X^H : Gr = Xr Xr^T + Xi Xi^T ; Gi = Xi Xr^T - Xr Xi^T
-    cgemm<TI>(st, gws, f.r(), f.i(), f.N, true, false, f.r(), f.i(), f.N, false, true, G.r(), G.i(cplx), T, T, T, (int)f.N, 1.0,
-              nullptr, nullptr, true);
-    tm.end();
+    gram(f, cplx, G);
     tm.begin("eigh");
     if (want_vectors) R.Z.ensure((size_t)T * T, cplx);
     R.s.ensure((size_t)T);
@@ -267,6 +272,11 @@ class Solver {
 
     // ------------------------------- two fields ------------------------------------------------
     const FieldData<TI>& B = fields[1];
+    static const bool one_sided_on = [] { const char* e = std::getenv("XMCA_ONE_SIDED"); return !(e && e[0] == '0'); }();
+    if (one_sided_on && Ra.reduced && B.N > B.T) {
+      solve_one_sided(A, B, cplx, Ra, n_vec_req, out);
+      return;
+    }
     reduce_field(B, cplx, Rb, G, &out.evd_info[1]);
     const int ra = Ra.r, rb = Rb.r;
     const int rank = std::min(ra, rb);
@@ -348,6 +358,64 @@ class Solver {
   }
 
   // -------------------------------------------------------------------------------------------------------------
+  // Two fields, both wider than T: only ONE of them is decomposed.  With F_a = U_a S_a from G_a and the kernel
+  // K = F_a^H F_b / dof of the reference (array.py:553-566), K K^H = F_a^H (F_b F_b^H) F_a / dof^2 = F_a^H G_b F_a / dof^2:
+  // the Gram matrix of the second field enters as an operator and is never diagonalised (one T x T eigenproblem with
+  // vectors less per solve).  Left small singular vectors p_m and sigma_m^2 = eigenpairs of H = K K^H; in grid space
+  //   v_right,m ~ X~b^H (F_a p_m),    v_left,m ~ X~a^H (G_b F_a p_m) = dof C v_right,m     (rows normalised afterwards),
+  // which also fixes the shared phase gauge u^H C v = +sigma.
+  // -------------------------------------------------------------------------------------------------------------
+  void solve_one_sided(const FieldData<TI>& A, const FieldData<TI>& B, bool cplx, const Reduced& Ra, int n_vec_req, SolveResult& out) {
+    const int T = (int)A.T, ra = Ra.r;
+    const double dof = (double)(T - 1);
+    const int rank = ra;                       // = T = min(T, Nx, Ny)
+    out.rank = rank;
+    CPlanes Gb, M1, H, Ph;
+    gram(B, cplx, Gb);
+    tm.begin("kernel");
+    M1.ensure((size_t)ra * T, cplx);
+    H.ensure((size_t)ra * ra, cplx);
+    // M1 = (S_a Z_a) G_b ;  H = M1 (S_a Z_a)^H / dof^2
+    cgemm<double>(st, gws, Ra.Z.r(), Ra.Z.i(cplx), T, true, false, Gb.r(), Gb.i(cplx), T, true, false, M1.r(), M1.i(cplx), T, ra, T, T,
+                  1.0, Ra.s.get(), nullptr, false);
+    cgemm<double>(st, gws, M1.r(), M1.i(cplx), T, true, false, Ra.Z.r(), Ra.Z.i(cplx), T, false, true, H.r(), H.i(cplx), ra, ra, ra, T,
+                  1.0 / (dof * dof), nullptr, Ra.s.get(), true);
+    tm.end();
+    const int m = n_vec_req < 0 ? rank : std::min(n_vec_req, rank);
+    std::vector<double> lam;
+    tm.begin("kernel_svd");
+    if (m > 0) Ph.ensure((size_t)ra * ra, cplx);
+    hermitian_evd(st, ews, H.r(), H.i(cplx), ra, ra, lam, nullptr, m > 0 ? Ph.r() : nullptr, m > 0 ? Ph.i(cplx) : nullptr, ra,
+                  &out.evd_info[2]);
+    XMCA_HIP(hipStreamSynchronize(st));
+    tm.end();
+    out.sigma.resize(rank);
+    for (int i = 0; i < rank; ++i) out.sigma[i] = std::sqrt(std::max(lam[i], 0.0));
+    out.n_vec = m;
+    out.ldv[0] = A.N;
+    out.ldv[1] = B.N;
+    if (m == 0) return;
+    tm.begin("backproject");
+    // Th_a[m][t] = conj((F_a p_m)[t]) = ((Ph diag(s_a)) Z_a)[m][t] ;  Th_l = Th_a G_b  (G_b Hermitian)
+    CPlanes Ws, Tha, Thl;
+    Ws.ensure((size_t)m * ra, cplx);
+    Tha.ensure((size_t)m * T, cplx);
+    Thl.ensure((size_t)m * T, cplx);
+    XMCA_HIP(hipMemcpyAsync(Ws.r(), Ph.r(), sizeof(double) * (size_t)m * ra, hipMemcpyDeviceToDevice, st));
+    if (cplx) XMCA_HIP(hipMemcpyAsync(Ws.im.get(), Ph.im.get(), sizeof(double) * (size_t)m * ra, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(scale_kernel, ew_grid((int64_t)m * ra), dim3(EW_BLOCK), 0, st, Ws.r(), Ws.i(cplx), (int64_t)ra, m, ra, Ra.s.get(),
+                       0, 0);
+    cgemm<double>(st, gws, Ws.r(), Ws.i(cplx), ra, true, false, Ra.Z.r(), Ra.Z.i(cplx), T, true, false, Tha.r(), Tha.i(cplx), T, m, T, ra,
+                  1.0, nullptr, nullptr, false);
+    cgemm<double>(st, gws, Tha.r(), Tha.i(cplx), T, true, false, Gb.r(), Gb.i(cplx), T, true, false, Thl.r(), Thl.i(cplx), T, m, T, T, 1.0,
+                  nullptr, nullptr, false);
+    XMCA_HIP(hipStreamSynchronize(st));
+    back_project(B, cplx, Tha.r(), Tha.i(cplx), m, out.Vt[1]);
+    back_project(A, cplx, Thl.r(), Thl.i(cplx), m, out.Vt[0]);
+    tm.end();
+  }
+
+  // -------------------------------------------------------------------------------------------------------------
   // Analytic-signal models (solve(complexify=True) without extension) whose fields are all wider than T.
   // hilbert(x) = Phi D Phi^H x with Phi the m = T/2+1 retained Fourier vectors, so X~ = Phi D Phi^H X lives in an
   // m-dimensional subspace: G~ = X~ X~^H = Phi Gy Phi^H with Gy = D Phi^H (X X^T) Phi D (m x m).  The device therefore
@@ -375,10 +443,11 @@ class Solver {
     XMCA_HIP(hipGetLastError());
   }
 
-  void reduce_analytic(const FieldData<TI>& f, const Analytic& an, AReduced& R, EvdInfo* info, bool want_vectors) {
+  // Gy = D Phi^H (X X^T) Phi D   (m x m Hermitian, both triangles)
+  void analytic_gram(const FieldData<TI>& f, const Analytic& an, CPlanes& Gy) {
     const int T = (int)f.T, m = an.m;
     DevBuf<double> G;
-    CPlanes P1, Gy;
+    CPlanes P1;
     G.ensure((size_t)T * T);
     P1.ensure((size_t)T * m, true);
     Gy.ensure((size_t)m * m, true);
@@ -396,6 +465,13 @@ class Solver {
     cgemm<double>(st, gws, an.Phi.r(), an.Phi.im.get(), m, false, true, P1.r(), P1.im.get(), m, true, false, Gy.r(), Gy.im.get(), m, m, m,
                   T, 1.0, an.h.get(), an.h.get(), true);
     tm.end();
+    XMCA_HIP(hipStreamSynchronize(st));     // G, P1 are released on return
+  }
+
+  void reduce_analytic(const FieldData<TI>& f, const Analytic& an, AReduced& R, EvdInfo* info, bool want_vectors) {
+    const int m = an.m;
+    CPlanes Gy;
+    analytic_gram(f, an, Gy);
     tm.begin("eigh");
     if (want_vectors) R.Wh.ensure((size_t)m * m, true);
     R.s.ensure((size_t)m);
@@ -467,6 +543,49 @@ class Solver {
       return;
     }
     const FieldData<TI>& B = fields[1];
+    static const bool one_sided_on = [] { const char* e = std::getenv("XMCA_ONE_SIDED"); return !(e && e[0] == '0'); }();
+    if (one_sided_on) {
+      // second field as an operator (see solve_one_sided): H = (S_a Wh_a) Gy_b (S_a Wh_a)^H / dof^2
+      CPlanes Gyb, M1, H, Ph;
+      analytic_gram(B, an, Gyb);
+      tm.begin("kernel");
+      M1.ensure((size_t)m * m, true);
+      H.ensure((size_t)m * m, true);
+      cgemm<double>(st, gws, Ra.Wh.r(), Ra.Wh.im.get(), m, true, false, Gyb.r(), Gyb.im.get(), m, true, false, M1.r(), M1.im.get(), m, m, m,
+                    m, 1.0, Ra.s.get(), nullptr, false);
+      cgemm<double>(st, gws, M1.r(), M1.im.get(), m, true, false, Ra.Wh.r(), Ra.Wh.im.get(), m, false, true, H.r(), H.im.get(), m, m, m, m,
+                    1.0 / (dof * dof), nullptr, Ra.s.get(), true);
+      tm.end();
+      std::vector<double> lam;
+      tm.begin("kernel_svd");
+      if (n_vec > 0) Ph.ensure((size_t)m * m, true);
+      hermitian_evd(st, ews, H.r(), H.im.get(), m, m, lam, nullptr, n_vec > 0 ? Ph.r() : nullptr, n_vec > 0 ? Ph.im.get() : nullptr, m,
+                    &out.evd_info[2]);
+      XMCA_HIP(hipStreamSynchronize(st));
+      tm.end();
+      for (int i = 0; i < m; ++i) out.sigma[i] = std::sqrt(std::max(lam[i], 0.0));
+      out.ldv[0] = A.N;
+      out.ldv[1] = B.N;
+      if (n_vec == 0) return;
+      tm.begin("backproject");
+      // E_right = (Ph diag(s_a)) Wh_a (rows = conj of the subspace coefficients of F_a p_m),  E_left = E_right Gy_b
+      CPlanes Ws, Er, El;
+      Ws.ensure((size_t)nv * m, true);
+      Er.ensure((size_t)nv * m, true);
+      El.ensure((size_t)nv * m, true);
+      XMCA_HIP(hipMemcpyAsync(Ws.r(), Ph.r(), sizeof(double) * (size_t)nv * m, hipMemcpyDeviceToDevice, st));
+      XMCA_HIP(hipMemcpyAsync(Ws.im.get(), Ph.im.get(), sizeof(double) * (size_t)nv * m, hipMemcpyDeviceToDevice, st));
+      hipLaunchKernelGGL(scale_kernel, ew_grid((int64_t)nv * m), dim3(EW_BLOCK), 0, st, Ws.r(), Ws.im.get(), (int64_t)m, nv, m, Ra.s.get(),
+                         0, 0);
+      cgemm<double>(st, gws, Ws.r(), Ws.im.get(), m, true, false, Ra.Wh.r(), Ra.Wh.im.get(), m, true, false, Er.r(), Er.im.get(), m, nv, m,
+                    m, 1.0, nullptr, nullptr, false);
+      cgemm<double>(st, gws, Er.r(), Er.im.get(), m, true, false, Gyb.r(), Gyb.im.get(), m, true, false, El.r(), El.im.get(), m, nv, m, m,
+                    1.0, nullptr, nullptr, false);
+      analytic_project(B, an, Er.r(), Er.im.get(), nv, n_vec, out.Vt[1]);
+      analytic_project(A, an, El.r(), El.im.get(), nv, n_vec, out.Vt[0]);
+      tm.end();
+      return;
+    }
     reduce_analytic(B, an, Rb, &out.evd_info[1], true);
     // K = S_a Wh_a Wh_b^H S_b / dof   (m x m)
     CPlanes K, H, Ph, Qh;
