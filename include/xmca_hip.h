@@ -124,6 +124,10 @@ int xmca_gemm(xmca_handle* h, const void* A, int64_t lda, int a_kfast, const voi
 /* Hermitian eigendecomposition of an n x n host matrix (interleaved complex when is_complex):
  * lam (n, descending) and Zh (n x n, row i = conj(u_i)); info[0] = sweeps, info[1] = tile, info[2] = slots. */
 int xmca_eigh(xmca_handle* h, const double* A, int n, int is_complex, double* lam, double* Zh, int* info);
+/* Blocked Cholesky of an n x n Hermitian host matrix (interleaved complex when is_complex): R (n x n, upper
+ * triangular, row-major, same element layout) with R^H R = A + rel_shift * max(diag A) * I; *ok = 0 when a pivot was
+ * not positive.  (The device routine behind the values-only two-field solve; exported for the kernel tests.) */
+int xmca_cholesky(xmca_handle* h, const double* A, int n, int is_complex, double rel_shift, double* R, int* ok);
 /* Time `reps` Gram products G = X X^T of the resident field `side` with hipEvents on the library's stream;
  * avg_ms = mean duration of one product (all launches it needs), kernel_ms = mean duration of the MFMA
  * kernel launches alone, flops = useful flops of one product, T (T+1) N. */

@@ -113,3 +113,33 @@ def test_philox_normals(hip):
     assert abs(np.corrcoef(x, z)[0, 1]) < 5 / np.sqrt(n)      # independent across runs
     w = hip.surrogate(1000, seed=42, run=3, side=1)
     assert np.array_equal(w, x[:1000])                        # prefix property (length independent)
+
+
+# ----------------------------------------------------------------------------------------------
+# blocked Cholesky (values-only two-field solves)
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,cplx", [(1, False), (5, False), (64, False), (65, True), (200, True), (333, False), (700, True)])
+def test_cholesky_matches_numpy(hip, n, cplx):
+    rng = np.random.default_rng(100 + n)
+    X = rng.standard_normal((n, 2 * n + 3))
+    if cplx:
+        X = X + 1j * rng.standard_normal(X.shape)
+    A = X @ X.conj().T
+    R, ok = hip.cholesky(A)
+    assert ok
+    ref = np.linalg.cholesky(A).conj().T                 # upper factor
+    assert np.allclose(np.tril(R, -1), 0.0)
+    assert np.max(np.abs(R - ref)) / np.max(np.abs(ref)) < 1e-11
+    assert np.max(np.abs(R.conj().T @ R - A)) / np.max(np.abs(A)) < 1e-13
+
+
+def test_cholesky_semidefinite_needs_the_shift(hip):
+    rng = np.random.default_rng(7)
+    X = rng.standard_normal((90, 300))
+    X -= X.mean(axis=0)                                   # centered in time: the Gram matrix is singular
+    A = X @ X.T
+    R, ok = hip.cholesky(A, rel_shift=1e-13)
+    assert ok
+    assert np.max(np.abs(R.T @ R - A)) / np.max(np.abs(A)) < 1e-12
+    _, ok = hip.cholesky(-A)                              # not positive: reported, no exception
+    assert not ok

@@ -155,3 +155,30 @@ def test_values_only_solve(hip):
     rank, sig, V = device_solve(hip, fields, False, n_vec=0)
     rank2, sig2, _ = device_solve(hip, fields, False)
     assert V[0].shape[1] == 0 and np.allclose(sig, sig2, rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("complexify", [False, True])
+def test_values_only_cholesky_route_matches_decomposition_route(complexify):
+    """rule_n without rotation needs singular values only: the Cholesky route (no field is diagonalised) must give the
+    spectra of the eigen-decomposition route (XMCA_CHOLESKY=0) - separate processes, the switch is read once."""
+    import json
+    import subprocess
+    import sys
+    code = ("import json, numpy as np\n"
+            "from xmca_amd import _hip\n"
+            "h = _hip.Handle(0)\n"
+            "sp, kept = h.rule_n(60, 300, 200, 2, %r, False, 0, 0, 1e-8, 0, 2, 11, np.float64, 60)\n"
+            "print(json.dumps({'sp': sp.tolist(), 'stages': sorted(h.timings())}))\n" % complexify)
+    REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for flag in ("1", "0"):
+        env = dict(os.environ, XMCA_CHOLESKY=flag)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=REPO, timeout=300)
+        assert r.returncode == 0, r.stderr
+        out[flag] = json.loads(r.stdout.strip().splitlines()[-1])
+    a, b = np.array(out["1"]["sp"]), np.array(out["0"]["sp"])
+    n_sig = 30 if complexify else 58                       # meaningful modes (analytic signal: m = T/2 + 1, minus the mean)
+    assert np.max(np.abs(a[:, :n_sig] - b[:, :n_sig]) / b[:, :n_sig]) < 1e-9
+    assert np.all(np.abs(a[:, n_sig:] - b[:, n_sig:]) < 1e-5 * b[:, :1])
+    assert "cholesky" in out["1"]["stages"] and "eigh" not in out["1"]["stages"]             # no field decomposition at all
+    assert "eigh" in out["0"]["stages"] and "cholesky" not in out["0"]["stages"]

@@ -48,6 +48,7 @@ SIGNATURES = {
     "xmca_gemm": (_c_int, [_vp, _vp, _c_i64, _c_int, _vp, _c_i64, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_dbl,
                            _c_int, _c_int, _c_int]),
     "xmca_eigh": (_c_int, [_vp, _vp, _c_int, _c_int, _vp, _vp, _vp]),
+    "xmca_cholesky": (_c_int, [_vp, _vp, _c_int, _c_int, _c_dbl, _vp, ctypes.POINTER(_c_int)]),
     "xmca_bench_gram": (_c_int, [_vp, _c_int, _c_int, _dp, _dp, _dp]),
     "xmca_bench_gemm": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _dp]),
 }
@@ -309,6 +310,17 @@ class Handle:
         self._check(self._lib.xmca_eigh(self._h, _ptr(Ad), n, int(cplx), _ptr(lam), _ptr(Zh), _ptr(info)))
         self.last_eigh_info = {"sweeps": int(info[0]), "tile": int(info[1]), "slots": int(info[2])}
         return lam, Zh.conj().T
+
+    def cholesky(self, A, rel_shift=0.0):
+        """Returns (R upper triangular with R^H R = A + rel_shift max(diag A) I, ok)."""
+        A = np.asarray(A)
+        cplx = np.iscomplexobj(A)
+        Ad = np.ascontiguousarray(A, dtype=np.complex128 if cplx else np.float64)
+        n = Ad.shape[0]
+        R = np.empty((n, n), dtype=Ad.dtype)
+        ok = _c_int(0)
+        self._check(self._lib.xmca_cholesky(self._h, _ptr(Ad), n, int(cplx), float(rel_shift), _ptr(R), ctypes.byref(ok)))
+        return R, bool(ok.value)
 
     def bench_gemm(self, M, N, K, dtype, a_kfast=True, b_nfast=True, upper_only=False, splits=0, reps=5):
         """ms per product C = op(A) op(B) on device-resident random operands."""

@@ -8,6 +8,7 @@
 
 #include "common.h"
 #include "gemm.h"
+#include "cholesky.h"
 #include "jacobi.h"
 #include "kernels.h"
 #include "rotate.h"
@@ -83,7 +84,8 @@ struct FieldData {
 template <typename TI>
 void cgemm(hipStream_t st, GemmWorkspace& ws, const TI* Ar, const TI* Ai, int64_t lda, bool a_kfast, bool conjA, const TI* Br,
            const TI* Bi, int64_t ldb, bool b_nfast, bool conjB, double* Cr, double* Ci, int64_t ldc, int M, int N, int K,
-           double alpha, const double* row_scale, const double* col_scale, bool herm) {
+           double alpha, const double* row_scale, const double* col_scale, bool herm, double beta0 = 0.0) {
+  // beta0: C = ... + beta0 * C (both planes)
   GemmOpts o;
   o.a_kfast = a_kfast;
   o.b_nfast = b_nfast;
@@ -92,7 +94,7 @@ void cgemm(hipStream_t st, GemmWorkspace& ws, const TI* Ar, const TI* Ai, int64_
   o.upper_only = herm;
   const double sa = conjA ? -1.0 : 1.0, sb = conjB ? -1.0 : 1.0;
   // real part: Ar Br - sa sb Ai Bi
-  o.alpha = alpha; o.beta = 0.0; o.mirror = herm ? 1 : 0;
+  o.alpha = alpha; o.beta = beta0; o.mirror = herm ? 1 : 0;
   gemm<TI, double>(st, ws, Ar, lda, Br, ldb, Cr, ldc, M, N, K, o);
   if (Ai && Bi) {
     o.alpha = -sa * sb * alpha; o.beta = 1.0;
@@ -103,16 +105,70 @@ void cgemm(hipStream_t st, GemmWorkspace& ws, const TI* Ar, const TI* Ai, int64_
   o.mirror = herm ? -1 : 0;
   bool first = true;
   if (Bi) {
-    o.alpha = sb * alpha; o.beta = 0.0;
+    o.alpha = sb * alpha; o.beta = beta0;
     gemm<TI, double>(st, ws, Ar, lda, Bi, ldb, Ci, ldc, M, N, K, o);
     first = false;
   }
   if (Ai) {
-    o.alpha = sa * alpha; o.beta = first ? 0.0 : 1.0;
+    o.alpha = sa * alpha; o.beta = first ? beta0 : 1.0;
     gemm<TI, double>(st, ws, Ai, lda, Br, ldb, Ci, ldc, M, N, K, o);
     first = false;
   }
-  if (first) XMCA_HIP(hipMemsetAsync(Ci, 0, sizeof(double) * (size_t)M * ldc, st));
+  if (first && beta0 == 0.0) XMCA_HIP(hipMemsetAsync(Ci, 0, sizeof(double) * (size_t)M * ldc, st));
+}
+
+// Blocked Cholesky G + delta I = R^H R (R upper triangular) in place on the planes of an n x n Hermitian matrix whose
+// upper triangle is valid; delta = rel_shift * max diag (semi-definite Gram matrices of centered / analytic fields).
+// On return the strictly lower triangle is zero, so R is a dense GEMM operand.  Returns false when a pivot was not
+// positive (the caller then takes the eigen-decomposition route).  Panels of CHOL_NB columns: diagonal block and its
+// inverse in one workgroup, row panel R12 = R11^{-H} A12 and trailing update A22 -= R12^H R12 as MFMA GEMMs.
+inline bool cholesky_upper(hipStream_t st, GemmWorkspace& ws, double* Gr, double* Gi, int n, int64_t ld, double rel_shift) {
+  const bool cplx = Gi != nullptr;
+  DevBuf<double> rinv_r, rinv_i, tmp_r, tmp_i;
+  DevBuf<unsigned long long> mx;
+  DevBuf<int> fail;
+  rinv_r.ensure((size_t)CHOL_NB * CHOL_NB);
+  if (cplx) rinv_i.ensure((size_t)CHOL_NB * CHOL_NB);
+  tmp_r.ensure((size_t)CHOL_NB * n);
+  if (cplx) tmp_i.ensure((size_t)CHOL_NB * n);
+  XMCA_HIP(hipMemsetAsync(mx.ensure(1), 0, sizeof(unsigned long long), st));
+  XMCA_HIP(hipMemsetAsync(fail.ensure(1), 0, sizeof(int), st));
+  hipLaunchKernelGGL(chol_max_diag_kernel, dim3(std::min(ceil_div(n, 256), 64)), dim3(256), 0, st, Gr, ld, n, mx.get());
+  unsigned long long bits = 0;
+  XMCA_HIP(hipMemcpyAsync(&bits, mx.get(), sizeof(bits), hipMemcpyDeviceToHost, st));
+  XMCA_HIP(hipStreamSynchronize(st));
+  double maxdiag = 0.0;
+  std::memcpy(&maxdiag, &bits, sizeof(double));
+  if (!(maxdiag > 0.0) || !std::isfinite(maxdiag)) return false;
+  hipLaunchKernelGGL(chol_shift_diag_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, Gr, ld, n, rel_shift * maxdiag);
+  for (int k0 = 0; k0 < n; k0 += CHOL_NB) {
+    const int nb = std::min(CHOL_NB, n - k0), rest = n - k0 - nb;
+    if (cplx)
+      hipLaunchKernelGGL((chol_diag_kernel<true>), dim3(1), dim3(256), 0, st, Gr, Gi, ld, k0, nb, rinv_r.get(), rinv_i.get(), fail.get());
+    else
+      hipLaunchKernelGGL((chol_diag_kernel<false>), dim3(1), dim3(256), 0, st, Gr, (double*)nullptr, ld, k0, nb, rinv_r.get(),
+                         (double*)nullptr, fail.get());
+    XMCA_HIP(hipGetLastError());
+    if (rest <= 0) break;
+    const int64_t o12 = (int64_t)k0 * ld + k0 + nb, o22 = (int64_t)(k0 + nb) * ld + k0 + nb;
+    // R12 = Rinv^H A12   (nb x rest)
+    cgemm<double>(st, ws, rinv_r.get(), cplx ? rinv_i.get() : nullptr, CHOL_NB, false, true, Gr + o12, cplx ? Gi + o12 : nullptr, ld,
+                  true, false, tmp_r.get(), cplx ? tmp_i.get() : nullptr, rest, nb, rest, nb, 1.0, nullptr, nullptr, false);
+    hipLaunchKernelGGL(chol_place_kernel, ew_grid((int64_t)nb * rest), dim3(EW_BLOCK), 0, st, tmp_r.get(), (int64_t)rest, Gr, ld, k0,
+                       k0 + nb, nb, rest);
+    if (cplx)
+      hipLaunchKernelGGL(chol_place_kernel, ew_grid((int64_t)nb * rest), dim3(EW_BLOCK), 0, st, tmp_i.get(), (int64_t)rest, Gi, ld, k0,
+                         k0 + nb, nb, rest);
+    // A22 -= R12^H R12   (upper block triangle, mirrored)
+    cgemm<double>(st, ws, tmp_r.get(), cplx ? tmp_i.get() : nullptr, rest, false, true, tmp_r.get(), cplx ? tmp_i.get() : nullptr, rest,
+                  true, false, Gr + o22, cplx ? Gi + o22 : nullptr, ld, rest, rest, nb, -1.0, nullptr, nullptr, true, 1.0);
+  }
+  hipLaunchKernelGGL(chol_zero_lower_kernel, ew_grid((int64_t)n * n), dim3(EW_BLOCK), 0, st, Gr, Gi, ld, n);
+  XMCA_HIP(hipGetLastError());
+  int failed = 0;
+  XMCA_HIP(hipMemcpyAsync(&failed, fail.get(), sizeof(int), hipMemcpyDeviceToHost, st));
+  XMCA_HIP(hipStreamSynchronize(st));
+  return failed == 0;
 }
 
 template <typename TO>
@@ -221,6 +277,18 @@ class Solver {
     out.cplx = cplx;
     Reduced Ra, Rb;
     CPlanes G;
+    if (n_fields == 2 && n_vec_req == 0 && A.N > A.T && fields[1].N > fields[1].T && cholesky_enabled()) {
+      CPlanes Ga, Gb;
+      gram(A, cplx, Ga);
+      gram(fields[1], cplx, Gb);
+      if (values_by_cholesky(Ga, Gb, T, cplx, dof, out)) {
+        out.rank = T;
+        out.n_vec = 0;
+        out.ldv[0] = A.N;
+        out.ldv[1] = fields[1].N;
+        return;
+      }
+    }
     reduce_field(A, cplx, Ra, G, &out.evd_info[0], n_fields == 2 || n_vec_req != 0);
 
     if (n_fields == 1) {
@@ -355,6 +423,44 @@ class Solver {
     project_side(A, B, cplx, Ra, Rb, Ph, Qh, ra, rb, m, out.Vt[0]);   // V_left  from (F_b Q)
     project_side(B, A, cplx, Rb, Ra, Qh, Ph, rb, ra, m, out.Vt[1]);   // V_right from (F_a P)
     tm.end();
+  }
+
+  // -------------------------------------------------------------------------------------------------------------
+  // Singular values only (rule_n without rotation) of two wide fields: no field is diagonalised at all.  With the
+  // Cholesky factor G_a + delta I = R^H R (R^H = F_a times a unitary matrix), sigma^2 dof^2 = eig(R G_b R^H): one blocked
+  // Cholesky, two products and ONE values-only eigenproblem instead of an eigenproblem with vectors plus one without.
+  // delta = 1e-13 max diag (2e-6 for f32 fields) makes the (centered, hence singular) Gram matrix definite; it moves
+  // sigma^2 by that much, relative.
+  // Returns false (nothing written) when the factorisation meets a non-positive pivot.
+  // -------------------------------------------------------------------------------------------------------------
+  static bool cholesky_enabled() {
+    static const bool on = [] { const char* e = std::getenv("XMCA_CHOLESKY"); return !(e && e[0] == '0'); }();
+    return on;
+  }
+  bool values_by_cholesky(CPlanes& Ga, CPlanes& Gb, int n, bool cplx, double dof, SolveResult& out) {
+    tm.begin("cholesky");
+    // (f32 fields: their Gram matrix carries f32 accumulation noise of ~1e-7 max diag, also below zero)
+    const bool ok = cholesky_upper(st, gws, Ga.r(), Ga.i(cplx), n, n, std::is_same<TI, float>::value ? 2e-6 : 1e-13);
+    tm.end();
+    if (!ok) return false;
+    CPlanes M1, H;
+    M1.ensure((size_t)n * n, cplx);
+    H.ensure((size_t)n * n, cplx);
+    tm.begin("kernel");
+    // M1 = R G_b ;  H = M1 R^H / dof^2
+    cgemm<double>(st, gws, Ga.r(), Ga.i(cplx), n, true, false, Gb.r(), Gb.i(cplx), n, true, false, M1.r(), M1.i(cplx), n, n, n, n, 1.0,
+                  nullptr, nullptr, false);
+    cgemm<double>(st, gws, M1.r(), M1.i(cplx), n, true, false, Ga.r(), Ga.i(cplx), n, false, true, H.r(), H.i(cplx), n, n, n, n,
+                  1.0 / (dof * dof), nullptr, nullptr, true);
+    tm.end();
+    std::vector<double> lam;
+    tm.begin("kernel_svd");
+    hermitian_evd(st, ews, H.r(), H.i(cplx), n, n, lam, nullptr, nullptr, nullptr, n, &out.evd_info[2]);
+    XMCA_HIP(hipStreamSynchronize(st));
+    tm.end();
+    if ((int)out.sigma.size() < n) out.sigma.assign(n, 0.0);
+    for (int i = 0; i < n; ++i) out.sigma[i] = std::sqrt(std::max(lam[i], 0.0));
+    return true;
   }
 
   // -------------------------------------------------------------------------------------------------------------
@@ -533,6 +639,16 @@ class Solver {
     out.n_vec = n_vec;
     out.sigma.assign(T, 0.0);
     AReduced Ra, Rb;
+    if (n_fields == 2 && n_vec == 0 && cholesky_enabled()) {
+      CPlanes Gya, Gyb;
+      analytic_gram(A, an, Gya);
+      analytic_gram(fields[1], an, Gyb);
+      if (values_by_cholesky(Gya, Gyb, m, true, dof, out)) {      // sigma[m..T) stay exact zeros
+        out.ldv[0] = A.N;
+        out.ldv[1] = fields[1].N;
+        return;
+      }
+    }
     reduce_analytic(A, an, Ra, &out.evd_info[0], n_fields == 2 || n_vec != 0);
     if (n_fields == 1) {
       for (int i = 0; i < m; ++i) out.sigma[i] = std::max(Ra.lam[i], 0.0) / dof;

@@ -579,6 +579,31 @@ int xmca_gemm(xmca_handle* h, const void* A, int64_t lda, int a_kfast, const voi
   API_END(h)
 }
 
+int xmca_cholesky(xmca_handle* h, const double* A, int n, int is_complex, double rel_shift, double* R, int* ok) {
+  API_BEGIN(h)
+  XMCA_CHECK(A && R && ok && n >= 1, XMCA_ERR_INVALID, "cholesky: bad arguments");
+  const bool cplx = is_complex != 0;
+  const size_t nn = (size_t)n * n;
+  DevBuf<double> raw, rout;
+  CPlanes Ap;
+  Ap.ensure(nn, cplx);
+  if (cplx) {
+    XMCA_HIP(hipMemcpyAsync(raw.ensure(2 * nn), A, sizeof(double) * 2 * nn, hipMemcpyHostToDevice, h->st));
+    hipLaunchKernelGGL((split_complex_kernel<double, double>), ew_grid((int64_t)nn), dim3(EW_BLOCK), 0, h->st, raw.get(), Ap.r(),
+                       Ap.im.get(), (int64_t)nn);
+  } else {
+    XMCA_HIP(hipMemcpyAsync(Ap.r(), A, sizeof(double) * nn, hipMemcpyHostToDevice, h->st));
+  }
+  *ok = cholesky_upper(h->st, h->gws, Ap.r(), Ap.i(cplx), n, n, rel_shift) ? 1 : 0;
+  const size_t no = nn * (cplx ? 2 : 1);
+  hipLaunchKernelGGL((pack_rows_kernel<double>), ew_grid((int64_t)nn), dim3(EW_BLOCK), 0, h->st, Ap.r(), Ap.i(cplx), (int64_t)n, n, n,
+                     rout.ensure(no), 0);
+  XMCA_HIP(hipGetLastError());
+  XMCA_HIP(hipMemcpyAsync(R, rout.get(), sizeof(double) * no, hipMemcpyDeviceToHost, h->st));
+  XMCA_HIP(hipStreamSynchronize(h->st));
+  API_END(h)
+}
+
 int xmca_eigh(xmca_handle* h, const double* A, int n, int is_complex, double* lam, double* Zh, int* info) {
   API_BEGIN(h)
   XMCA_CHECK(A && n >= 1 && lam, XMCA_ERR_INVALID, "eigh: bad arguments");
