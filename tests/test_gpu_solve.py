@@ -182,3 +182,28 @@ def test_values_only_cholesky_route_matches_decomposition_route(complexify):
     assert np.all(np.abs(a[:, n_sig:] - b[:, n_sig:]) < 1e-5 * b[:, :1])
     assert "cholesky" in out["1"]["stages"] and "eigh" not in out["1"]["stages"]             # no field decomposition at all
     assert "eigh" in out["0"]["stages"] and "cholesky" not in out["0"]["stages"]
+
+
+@pytest.mark.parametrize("shape_a,shape_b,cplx,dtype,tol", [
+    ((2, 5), None, False, np.float64, 1e-10), ((3, 1), None, False, np.float64, 1e-10), ((5, 3), None, False, np.float64, 1e-10),
+    ((4, 4), None, False, np.float64, 1e-10), ((2, 2), (2, 3), False, np.float64, 1e-10), ((2, 1), (2, 1), False, np.float64, 1e-10),
+    ((6, 2), (6, 9), False, np.float64, 1e-10), ((10, 3), (10, 3), True, np.float64, 1e-10), ((7, 20), None, True, np.float64, 1e-10),
+    ((3, 10), (3, 12), True, np.float64, 1e-10), ((65, 64), None, False, np.float64, 1e-10),
+    ((64, 65), (64, 130), False, np.float64, 1e-9), ((33, 200), (33, 40), True, np.float64, 1e-10),
+    ((40, 7), (40, 300), False, np.float64, 1e-10), ((129, 500), (129, 128), False, np.float32, 1e-5)])
+def test_small_and_ragged_shapes_match_oracle(shape_a, shape_b, cplx, dtype, tol):
+    """tiny, square, tall, wide and mixed (one field narrower than T, the other wider) inputs through the whole class:
+    every branch of the field reduction (dual / primal / unreduced) against the numpy restatement."""
+    from oracle import ref_numpy as O
+    from xmca_amd.array import MCA
+    rng = np.random.default_rng(sum(shape_a) + 17)
+    fields = [rng.standard_normal(shape_a).astype(dtype)]
+    if shape_b is not None:
+        fields.append(rng.standard_normal(shape_b).astype(dtype))
+    m = MCA(*fields)
+    m.solve(complexify=cplx)
+    ref = O.OracleModel(*fields).solve(complexify=cplx)["singular_values"]
+    s = m._singular_values
+    assert len(s) == len(ref)
+    keep = ref > 1e-8 * ref[0]
+    assert np.max(np.abs(s[keep] - ref[keep]) / ref[keep]) < tol
