@@ -1142,7 +1142,8 @@ __global__ __launch_bounds__(256, jacobi_fused_wgs_per_cu<NT>()) void jacobi_fus
                                                                     double* Jr_next, double* Ji_next, double* Dr_next,
                                                                     double* Di_next, double tol, const double* scal,
                                                                     unsigned long long* sweep_off, int max_sweeps, int cross_only,
-                                                                    int S, int ld, unsigned int* work_counter, int zch, int n_static) {
+                                                                    int S, int ld, unsigned int* work_counter, int zch, int n_static,
+                                                                    int exile_ncu) {
   __shared__ union U {
     JacTileSmem<NT, CPLX> t;
     JacUpdSmem<NT, CPLX> u;
@@ -1167,8 +1168,19 @@ __global__ __launch_bounds__(256, jacobi_fused_wgs_per_cu<NT>()) void jacobi_fus
 #ifdef XMCA_JAC_PROF_NOUPD
   return;
 #endif
+  // Worker numbering.  exile_ncu > 0 (eigenvalues-only solves: the update is half as long as the tile-solve chain):
+  // blocks b, b + #CU, b + 2 #CU, ... land on the same CU (dispatch order observed on MI355X, scripts/probes/placement.cpp),
+  // so the workers with b % #CU < S would share a CU with a tile solve; they leave, and the others are renumbered
+  // densely.  The placement only steers who works - any assignment gives the same result.
+  int worker = (int)blockIdx.x < S ? -1 : (int)blockIdx.x - S, n_workers = (int)gridDim.x - S;
+  if (exile_ncu > 0) {
+    auto dense = [&](const int B) { return (B / exile_ncu) * (exile_ncu - S) + max(0, B % exile_ncu - S); };   // workers below block B
+    if ((int)blockIdx.x >= S && (int)blockIdx.x % exile_ncu < S) return;
+    n_workers = dense((int)gridDim.x);
+    if (worker >= 0) worker = dense((int)blockIdx.x);
+  }
   jacobi_persistent_update<NT, CPLX>(sm.u, slot, work_counter, Gr_in, Gi_in, Gr_out, Gi_out, Zr_in, Zi_in, Zr_out, Zi_out, Jr, Ji, Dr,
-                                     Di, S, ld, zch, n_static, (int)blockIdx.x < S ? -1 : (int)blockIdx.x - S, (int)gridDim.x - S);
+                                     Di, S, ld, zch, n_static, worker, n_workers);
 }
 
 __global__ void jacobi_diag_kernel(const double* __restrict__ Gr, int npad, double* __restrict__ d) {
@@ -1309,6 +1321,14 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
   const int n_workers = fused_grid - S;
   // eigenvector tiles handed out statically per worker (the G tiles always are)
   const int n_static = n_workers <= 0 ? 0 : (int)((int64_t)S * zch2 * static_pct / 100 / n_workers);
+  // eigenvalues only: the tile solves get their CUs to themselves (XMCA_JACOBI_EXILE=0 disables, =2 forces it always)
+  static const int exile_mode = [] { const char* e = std::getenv("XMCA_JACOBI_EXILE"); return e ? std::atoi(e) : 1; }();
+  const int ncu = resident_wgs / jacobi_fused_wgs_per_cu<NT>();
+  // (measured: eigenvalues of a 2920^2 real matrix 57.5 -> 51.8 ms; with four workgroups per CU - the 32 x 32 complex
+  //  tiles - a quarter of the workers would leave and the solve gets slower, 86 -> 95 ms at n = 2501)
+  const bool exile = (exile_mode == 2 || (exile_mode == 1 && !want_z && jacobi_fused_wgs_per_cu<NT>() == 2)) &&
+                     fused_grid == resident_wgs && S < ncu / 2;
+  const int exile_ncu = exile ? ncu : 0;
   if (lookahead) {
     ws.work.ensure((size_t)max_sweeps * rounds);
     XMCA_HIP(hipMemsetAsync(ws.work.get(), 0, sizeof(unsigned int) * (size_t)max_sweeps * rounds, st));
@@ -1334,7 +1354,8 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
                            CPLX ? ws.J[par][1].get() : nullptr, ws.D[par][0].get(), CPLX ? ws.D[par][1].get() : nullptr,
                            ws.J[par ^ 1][0].get(), CPLX ? ws.J[par ^ 1][1].get() : nullptr, ws.D[par ^ 1][0].get(),
                            CPLX ? ws.D[par ^ 1][1].get() : nullptr, tile_tol, ws.scal.get(), ws.off.get() + next_slot,
-                           inner_cap, is_cross((r + 1) % rounds) ? 1 : 0, S, npad, ws.work.get() + round_no, zch2, n_static);
+                           inner_cap, is_cross((r + 1) % rounds) ? 1 : 0, S, npad, ws.work.get() + round_no, zch2, n_static,
+                           exile_ncu);
       }
 #ifdef XMCA_JAC_PROF
       if (lookahead && round_no == 300) {   // stamps of a typical (cross-block) round in the middle of the solve
