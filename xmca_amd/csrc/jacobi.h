@@ -90,6 +90,14 @@ __device__ long long jac_prof[JAC_PROF_WG * JAC_PROF_IT * JAC_PROF_ST];
 #else
 #define JAC_STAMP(k) do { } while (0)
 #endif
+// threads per workgroup of the tile kernels: 512 for the 64 x 64 real tiles (two waves per SIMD hide the LDS / f64 latency
+// of the rotation steps, four per SIMD with two workgroups per CU feed the matrix pipe), 256 for the 32 x 32 tiles
+#ifndef XMCA_JAC_THREADS64
+#define XMCA_JAC_THREADS64 512
+#endif
+template <int NT>
+constexpr int jac_threads() { return NT >= 64 ? XMCA_JAC_THREADS64 : 256; }
+
 // 1/sqrt(x) and 1/x for normal positive x, full double precision: hardware seed, three Newton steps
 __device__ __forceinline__ double jac_rsqrt(const double x) {
   double y = __builtin_amdgcn_rsq(x);
@@ -115,7 +123,7 @@ struct JacTileSmem {
   double Mi[CPLX ? NT : 1][CPLX ? NT + 1 : 1];
   double Vi[CPLX ? NT : 1][CPLX ? NT + 1 : 1];
   double rc[NT / 2], rsr[NT / 2], rsi[NT / 2];
-  double red[4];
+  double red[8];
   int flag;
 };
 template <int NT, bool CPLX>
@@ -131,6 +139,8 @@ __device__ __forceinline__ void jacobi_tile_evd_body(JacTileSmem<NT, CPLX>& sm, 
                                                      double tol, const double* __restrict__ scal,
                                                      unsigned long long* __restrict__ sweep_off, int max_sweeps,
                                                      const bool cross_only) {
+  constexpr int THR = jac_threads<NT>();
+  constexpr int NW = THR / 64;
   constexpr int H = NT / 2;
   constexpr int LD = NT + 1;
   auto& Mr = sm.Mr;
@@ -147,7 +157,7 @@ __device__ __forceinline__ void jacobi_tile_evd_body(JacTileSmem<NT, CPLX>& sm, 
   const double gscale = scal[0], abs_floor = scal[1];
   if constexpr (!PRELOADED) {
     const int64_t base = (int64_t)P * NT * ld + (int64_t)P * NT;
-    for (int e = tid; e < NT * NT; e += 256) {
+    for (int e = tid; e < NT * NT; e += THR) {
       const int i = e / NT, j = e % NT;
       Mr[i][j] = Gr[base + (int64_t)i * ld + j];
       Vr[i][j] = (i == j) ? 1.0 : 0.0;
@@ -163,7 +173,7 @@ __device__ __forceinline__ void jacobi_tile_evd_body(JacTileSmem<NT, CPLX>& sm, 
   // jacobi_offmax_kernel).  Not on the serial path of the fused rounds: PRELOADED callers skip it.
   if constexpr (!PRELOADED) {
     double mx = 0.0;
-    for (int e = tid; e < NT * NT; e += 256) {
+    for (int e = tid; e < NT * NT; e += THR) {
       const int i = e / NT, j = e % NT;
       if (i <= j) {
         double g2 = Mr[i][j] * Mr[i][j];
@@ -176,7 +186,7 @@ __device__ __forceinline__ void jacobi_tile_evd_body(JacTileSmem<NT, CPLX>& sm, 
     if ((tid & 63) == 0) red[tid >> 6] = mx;
     __syncthreads();
     if (tid == 0) {
-      mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+      for (int w = 1; w < NW; ++w) mx = fmax(mx, red[w]);   // (mx still holds this wave's = red[0])
       if (mx < HUGE_VAL) mx = sqrt(mx) / gscale;
       if (mx > 0.0) atomicMax(sweep_off, (unsigned long long)__double_as_longlong(mx));
     }
@@ -185,8 +195,8 @@ __device__ __forceinline__ void jacobi_tile_evd_body(JacTileSmem<NT, CPLX>& sm, 
   // Parallel-order cyclic Jacobi.  Thread t owns, for the whole kernel, the column pair k2 = t % H (for the
   // 2x2 blocks (k1, k2) it transforms and for the rows of V it rotates), so the rotation of k2 is read once per
   // step and only the k1 rotations are re-read per block: ~3x fewer LDS operations than a generic item loop.
-  constexpr int KSTRIDE = 256 / H;            // 8 (NT = 64) or 16 (NT = 32)
-  constexpr int NBLK = (H * H) / 256;         // 2x2 blocks per thread: 4 or 1
+  constexpr int KSTRIDE = THR / H;            // 8 (NT = 64) or 16 (NT = 32)
+  constexpr int NBLK = (H * H) / THR;         // 2x2 blocks per thread: 4 or 1
   constexpr int NROW = NT / KSTRIDE;          // rows of V per thread: 8 or 2
   const int k2 = tid % H, kb = tid / H, lane = tid & 63;
   // full mode: round-robin tournament over all NT indices (NT-1 steps).  cross mode: only the pairs (p, q) with p in
@@ -366,7 +376,7 @@ __device__ __forceinline__ void jacobi_tile_evd_body(JacTileSmem<NT, CPLX>& sm, 
   if (PRELOADED && tid == 0) jac_prof[((int)blockIdx.x * JAC_PROF_IT) * JAC_PROF_ST + 6] = (long long)__builtin_readcyclecounter();
 #endif
   const int64_t jb = (int64_t)P * NT * NT;
-  for (int e = tid; e < NT * NT; e += 256) {
+  for (int e = tid; e < NT * NT; e += THR) {
     const int i = e / NT, j = e % NT;
     Jr[jb + e] = Vr[i][j];
     Dr[jb + e] = Mr[i][j];          // J^H M J: diagonal only when the tile was swept to convergence
@@ -399,9 +409,10 @@ __device__ __forceinline__ void jacobi_update_body(JacUpdSmem<NT, CPLX>& sm, con
                                                    const double* __restrict__ Di, int S, int ld, const bool upper_store) {
   constexpr int LD = NT + 1;
   constexpr int HB = NT / 2;
+  constexpr int THR = jac_threads<NT>();
   constexpr int TPD = NT / 16;          // MFMA tiles per dimension
-  constexpr int NACC = TPD * TPD / 4;   // output tiles per wave
-  constexpr int EPT = NT * NT / 256;    // tile elements per thread
+  constexpr int NACC = TPD * TPD / (THR / 64);   // output tiles per wave
+  constexpr int EPT = NT * NT / THR;    // tile elements per thread
   auto& Ar = sm.Ar;
   auto& Br = sm.Br;
   auto& Ai = sm.Ai;
@@ -435,7 +446,7 @@ __device__ __forceinline__ void jacobi_update_body(JacUpdSmem<NT, CPLX>& sm, con
     // the diagonal tile was transformed by the tile solver itself (J_P^H G[P,P] J_P); move it to its destination blocks
     // upper_store: nothing ever reads a half-block below the block diagonal again (tiles are taken from the upper
     // triangle, diagonal tiles from D), so its off-diagonal quarter is written once, in whichever orientation is upper
-    for (int e = tid; e < NT * NT; e += 256) {
+    for (int e = tid; e < NT * NT; e += THR) {
       const int r = e / NT, c = e % NT;
       const int br = jacobi_dest_block(P, r / HB, S), bc = jacobi_dest_block(P, c / HB, S);
       if (upper_store && br > bc) continue;
@@ -452,7 +463,7 @@ __device__ __forceinline__ void jacobi_update_body(JacUpdSmem<NT, CPLX>& sm, con
   double jqr[EPT], jqi[CPLX ? EPT : 1];
 #pragma unroll
   for (int i = 0; i < EPT; ++i) {
-    const int e = tid + 256 * i;
+    const int e = tid + THR * i;
     Ar[e / NT][e % NT] = Jr[jpb + e];
     if constexpr (CPLX) Ai[e / NT][e % NT] = Ji[jpb + e];
     if (is_g) {
@@ -469,7 +480,7 @@ __device__ __forceinline__ void jacobi_update_body(JacUpdSmem<NT, CPLX>& sm, con
     const int64_t tbase = (int64_t)P * NT * ld + (int64_t)Qc * NT;
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
-      const int e = tid + 256 * i, r = e / NT, c = e % NT;
+      const int e = tid + THR * i, r = e / NT, c = e % NT;
       Br[r][c] = Sr[tbase + (int64_t)r * ld + c];
       if constexpr (CPLX) Bi[r][c] = Si[tbase + (int64_t)r * ld + c];
     }
@@ -512,7 +523,7 @@ __device__ __forceinline__ void jacobi_update_body(JacUpdSmem<NT, CPLX>& sm, con
     if (is_g) {
 #pragma unroll
       for (int i = 0; i < EPT; ++i) {
-        const int e = tid + 256 * i;
+        const int e = tid + THR * i;
         Ar[e / NT][e % NT] = jqr[i];
         if constexpr (CPLX) Ai[e / NT][e % NT] = jqi[i];
       }
@@ -523,7 +534,7 @@ __device__ __forceinline__ void jacobi_update_body(JacUpdSmem<NT, CPLX>& sm, con
       // Z'[dest(P,h) rows, chunk Qc] = X   (row segments of NT doubles)
 #pragma unroll
       for (int i = 0; i < EPT; ++i) {
-        const int e = tid + 256 * i, r = e / NT, c = e % NT;
+        const int e = tid + THR * i, r = e / NT, c = e % NT;
         const int dr = jacobi_dest_block(P, r / HB, S) * HB + r % HB;
         const int64_t o = (int64_t)dr * ld + (int64_t)Qc * NT + c;
         JAC_STORE(&Zr_out[o], Br[r][c]);
@@ -571,7 +582,7 @@ __device__ __forceinline__ void jacobi_update_body(JacUpdSmem<NT, CPLX>& sm, con
     // scatter to the next round's slots: the tile itself (rows) and its Hermitian mirror (columns read from LDS)
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
-      const int e = tid + 256 * i, r = e / NT, c = e % NT;
+      const int e = tid + THR * i, r = e / NT, c = e % NT;
       const int br = jacobi_dest_block(P, r / HB, S), bc = jacobi_dest_block(Q, c / HB, S);
       if (!upper_store || br < bc) {
         const int dr = br * HB + r % HB, dc = bc * HB + c % HB;
@@ -608,11 +619,13 @@ __device__ __forceinline__ void jacobi_assemble_next_diag(JacTileSmem<NT, CPLX>&
                                                           const double* __restrict__ Gr_in, const double* __restrict__ Gi_in,
                                                           const int ld, const double* __restrict__ Jr, const double* __restrict__ Ji,
                                                           const double* __restrict__ Dr, const double* __restrict__ Di) {
+  constexpr int THR = jac_threads<NT>();
+  constexpr int NW = THR / 64;
   constexpr int HB = NT / 2;
   constexpr int XT = (HB / 16) * (NT / 16);     // MFMA tiles of X (HB x NT): 8 or 2
-  constexpr int XPW = (XT + 3) / 4;             // per wave: 2 or 1
+  constexpr int XPW = (XT + NW - 1) / NW;       // per wave
   constexpr int YT = (HB / 16) * (HB / 16);     // MFMA tiles of Yq (HB x HB): 4 or 1
-  constexpr int EPT = NT * NT / 256;            // elements per thread of a full tile
+  constexpr int EPT = NT * NT / THR;            // elements per thread of a full tile
   constexpr int EPH = EPT / 2;                  // ... of a half tile (NT x HB) / of two quarters
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
   int A, hA, B, hB;
@@ -628,25 +641,25 @@ __device__ __forceinline__ void jacobi_assemble_next_diag(JacTileSmem<NT, CPLX>&
   double dbr[EPH / 2], dbi[CPLX ? EPH / 2 : 1]; // D_B[hB, hB] quarter
 #pragma unroll
   for (int i = 0; i < EPH; ++i) {
-    const int e = tid + 256 * i, r = e / HB, c = e % HB;
+    const int e = tid + THR * i, r = e / HB, c = e % HB;
     jar[i] = Jr[ja + (int64_t)r * NT + hA * HB + c];
     if constexpr (CPLX) jai[i] = Ji[ja + (int64_t)r * NT + hA * HB + c];
   }
 #pragma unroll
   for (int i = 0; i < EPT; ++i) {
-    const int e = tid + 256 * i, r = e / NT, c = e % NT;
+    const int e = tid + THR * i, r = e / NT, c = e % NT;
     tr[i] = Gr_in[tbase + (int64_t)r * ld + c];
     if constexpr (CPLX) ti[i] = Gi_in[tbase + (int64_t)r * ld + c];
   }
 #pragma unroll
   for (int i = 0; i < EPH; ++i) {
-    const int e = tid + 256 * i, r = e / HB, c = e % HB;
+    const int e = tid + THR * i, r = e / HB, c = e % HB;
     jbr[i] = Jr[jb + (int64_t)r * NT + hB * HB + c];
     if constexpr (CPLX) jbi[i] = Ji[jb + (int64_t)r * NT + hB * HB + c];
   }
 #pragma unroll
   for (int i = 0; i < EPH / 2; ++i) {
-    const int e = tid + 256 * i, r = e / HB, c = e % HB;
+    const int e = tid + THR * i, r = e / HB, c = e % HB;
     const int64_t oa = ja + (int64_t)(hA * HB + r) * NT + hA * HB + c, ob = jb + (int64_t)(hB * HB + r) * NT + hB * HB + c;
     dar[i] = Dr[oa];
     dbr[i] = Dr[ob];
@@ -655,13 +668,13 @@ __device__ __forceinline__ void jacobi_assemble_next_diag(JacTileSmem<NT, CPLX>&
   // A[:, 0..HB) <- J_A half, B <- T
 #pragma unroll
   for (int i = 0; i < EPH; ++i) {
-    const int e = tid + 256 * i, r = e / HB, c = e % HB;
+    const int e = tid + THR * i, r = e / HB, c = e % HB;
     su.Ar[r][c] = jar[i];
     if constexpr (CPLX) su.Ai[r][c] = jai[i];
   }
 #pragma unroll
   for (int i = 0; i < EPT; ++i) {
-    const int e = tid + 256 * i, r = e / NT, c = e % NT;
+    const int e = tid + THR * i, r = e / NT, c = e % NT;
     su.Br[r][c] = tr[i];
     if constexpr (CPLX) su.Bi[r][c] = ti[i];
   }
@@ -708,7 +721,7 @@ __device__ __forceinline__ void jacobi_assemble_next_diag(JacTileSmem<NT, CPLX>&
   }
 #pragma unroll
   for (int i = 0; i < EPH; ++i) {
-    const int e = tid + 256 * i, r = e / HB, c = e % HB;
+    const int e = tid + THR * i, r = e / HB, c = e % HB;
     su.Ar[r][c] = jbr[i];
     if constexpr (CPLX) su.Ai[r][c] = jbi[i];
   }
@@ -747,7 +760,7 @@ __device__ __forceinline__ void jacobi_assemble_next_diag(JacTileSmem<NT, CPLX>&
   }
 #pragma unroll
   for (int i = 0; i < EPH / 2; ++i) {
-    const int e = tid + 256 * i, r = e / HB, c = e % HB;
+    const int e = tid + THR * i, r = e / HB, c = e % HB;
     st.Mr[r][c] = dar[i];
     st.Mr[HB + r][HB + c] = dbr[i];
     if constexpr (CPLX) {
@@ -757,7 +770,7 @@ __device__ __forceinline__ void jacobi_assemble_next_diag(JacTileSmem<NT, CPLX>&
   }
 #pragma unroll
   for (int i = 0; i < EPT; ++i) {
-    const int e = tid + 256 * i;
+    const int e = tid + THR * i;
     st.Vr[e / NT][e % NT] = (e / NT == e % NT) ? 1.0 : 0.0;
     if constexpr (CPLX) st.Vi[e / NT][e % NT] = 0.0;
   }
@@ -765,7 +778,7 @@ __device__ __forceinline__ void jacobi_assemble_next_diag(JacTileSmem<NT, CPLX>&
 }
 
 template <int NT, bool CPLX>
-__global__ __launch_bounds__(256, 2) void jacobi_tile_evd_kernel(const double* Gr, const double* Gi, int ld, double* Jr, double* Ji,
+__global__ __launch_bounds__(jac_threads<NT>(), 2 * jac_threads<NT>() / 256) void jacobi_tile_evd_kernel(const double* Gr, const double* Gi, int ld, double* Jr, double* Ji,
                                                                  double* Dr, double* Di, double tol, const double* scal,
                                                                  unsigned long long* sweep_off, int max_sweeps, int cross_only) {
   __shared__ JacTileSmem<NT, CPLX> sm;
@@ -773,7 +786,7 @@ __global__ __launch_bounds__(256, 2) void jacobi_tile_evd_kernel(const double* G
 }
 
 template <int NT, bool CPLX>
-__global__ __launch_bounds__(256, 2) void jacobi_update_kernel(const double* Gr_in, const double* Gi_in, double* Gr_out,
+__global__ __launch_bounds__(jac_threads<NT>(), 2 * jac_threads<NT>() / 256) void jacobi_update_kernel(const double* Gr_in, const double* Gi_in, double* Gr_out,
                                                                double* Gi_out, const double* Zr_in, const double* Zi_in,
                                                                double* Zr_out, double* Zi_out, const double* Jr, const double* Ji,
                                                                const double* Dr, const double* Di, int S, int ld) {
@@ -841,10 +854,11 @@ __device__ __forceinline__ void jacobi_persistent_update(JacUpdSmem<NT, CPLX>& s
                                                          const int ld, const int zch, const int n_static, const int worker,
                                                          const int n_workers) {
   constexpr int HB = NT / 2;
+  constexpr int THR = jac_threads<NT>();
   constexpr int TPD = NT / 16;
-  constexpr int NACC = TPD * TPD / 4;
-  constexpr int EPT = NT * NT / 256;   // tile elements per thread = passes over the tile
-  constexpr int RP = 256 / NT;         // tile rows covered by one pass
+  constexpr int NACC = TPD * TPD / (THR / 64);
+  constexpr int EPT = NT * NT / THR;   // tile elements per thread = passes over the tile
+  constexpr int RP = THR / NT;         // tile rows covered by one pass
   static_assert(HB % RP == 0, "a pass must not straddle the two half-blocks");
   auto& Ar = sm.Ar;
   auto& Br = sm.Br;
@@ -896,13 +910,13 @@ __device__ __forceinline__ void jacobi_persistent_update(JacUpdSmem<NT, CPLX>& s
   };
   auto issue_PT = [&](const JacItem& it) {
     if (it.kind <= 0) return;
-    fetch(tP, rJr, rJi, voff_J, (unsigned int)(it.P * NT * NT), 256u);
+    fetch(tP, rJr, rJi, voff_J, (unsigned int)(it.P * NT * NT), (unsigned int)THR);
     const unsigned int tb = (unsigned int)(it.P * NT * ld + it.Q * NT);
     if (it.kind == 1) fetch(tT, rGr, rGi, voff_T, tb, (unsigned int)(RP * ld));
     else fetch(tT, rZr, rZi, voff_T, tb, (unsigned int)(RP * ld));
   };
   auto issue_Q = [&](const JacItem& it) {
-    if (it.kind == 1) fetch(tQ, rJr, rJi, voff_J, (unsigned int)(it.Q * NT * NT), 256u);
+    if (it.kind == 1) fetch(tQ, rJr, rJi, voff_J, (unsigned int)(it.Q * NT * NT), (unsigned int)THR);
   };
   // B <- A^H B   (A = J_P, B = tile), through registers
   auto mul_AhB = [&]() {
@@ -997,7 +1011,7 @@ __device__ __forceinline__ void jacobi_persistent_update(JacUpdSmem<NT, CPLX>& s
 #pragma unroll
       for (int i = 0; i < EPT; ++i) {
         const int br = jacobi_dest_block(P, (RP * i) / HB, S);
-        const unsigned int src = (unsigned int)(P * NT * NT + 256 * i) * 8u;
+        const unsigned int src = (unsigned int)(P * NT * NT + THR * i) * 8u;
         const unsigned int soff = (unsigned int)((br * HB + (RP * i) % HB) * ld) * 8u;
         if (br <= bc) {
           jac_st(jac_ld(rDr, voff_J, src), oGr, voff, soff);
@@ -1061,7 +1075,7 @@ __device__ __forceinline__ void jacobi_persistent_update(JacUpdSmem<NT, CPLX>& s
       const int P = cur.P, Q = cur.Q;
       // each quarter (hr, hc) goes out once, in the orientation that lies above the block diagonal of the next round
       // (uniform per quarter): as it is, or conjugate-transposed.  Either way a wave writes full row segments.
-      constexpr int QR = 256 / HB;          // quarter rows per pass
+      constexpr int QR = THR / HB;          // quarter rows per pass
       constexpr int QP = HB / QR;           // passes per quarter
       const int qrow = tid / HB, qcol = tid % HB;
       const unsigned int voff_q = (unsigned int)(qrow * ld + qcol) * 8u;
@@ -1135,7 +1149,7 @@ template <int NT>
 constexpr int jacobi_fused_wgs_per_cu() { return NT >= 64 ? 2 : XMCA_JAC_WGS32; }
 
 template <int NT, bool CPLX>
-__global__ __launch_bounds__(256, jacobi_fused_wgs_per_cu<NT>()) void jacobi_fused_round_kernel(const double* Gr_in, const double* Gi_in, double* Gr_out,
+__global__ __launch_bounds__(jac_threads<NT>(), jacobi_fused_wgs_per_cu<NT>() * jac_threads<NT>() / 256) void jacobi_fused_round_kernel(const double* Gr_in, const double* Gi_in, double* Gr_out,
                                                                     double* Gi_out, const double* Zr_in, const double* Zi_in,
                                                                     double* Zr_out, double* Zi_out, const double* Jr,
                                                                     const double* Ji, const double* Dr, const double* Di,
@@ -1293,13 +1307,13 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
   static const bool cross_on = [] { const char* e = std::getenv("XMCA_JACOBI_CROSS"); return !(e && e[0] == '0'); }();
   auto is_cross = [&](int round_in_sweep) { return cross_on && S > 1 && inner_cap == 1 && round_in_sweep != 0; };
   auto evd = [&](hipStream_t s, int gbuf, int par, int sweep_slot, int round_in_sweep) {
-    hipLaunchKernelGGL((jacobi_tile_evd_kernel<NT, CPLX>), dim3(S), dim3(256), 0, s, ws.G[gbuf][0].get(),
+    hipLaunchKernelGGL((jacobi_tile_evd_kernel<NT, CPLX>), dim3(S), dim3(jac_threads<NT>()), 0, s, ws.G[gbuf][0].get(),
                        CPLX ? ws.G[gbuf][1].get() : nullptr, npad, ws.J[par][0].get(), CPLX ? ws.J[par][1].get() : nullptr,
                        ws.D[par][0].get(), CPLX ? ws.D[par][1].get() : nullptr, tile_tol, ws.scal.get(),
                        ws.off.get() + sweep_slot, S == 1 ? 60 : inner_cap, is_cross(round_in_sweep) ? 1 : 0);
   };
   auto update = [&](hipStream_t s, int par, int grid) {
-    hipLaunchKernelGGL((jacobi_update_kernel<NT, CPLX>), dim3(grid), dim3(256), 0, s, ws.G[cur][0].get(),
+    hipLaunchKernelGGL((jacobi_update_kernel<NT, CPLX>), dim3(grid), dim3(jac_threads<NT>()), 0, s, ws.G[cur][0].get(),
                        CPLX ? ws.G[cur][1].get() : nullptr, ws.G[cur ^ 1][0].get(), CPLX ? ws.G[cur ^ 1][1].get() : nullptr,
                        ws.Z[cur][0].get(), CPLX ? ws.Z[cur][1].get() : nullptr, ws.Z[cur ^ 1][0].get(),
                        CPLX ? ws.Z[cur ^ 1][1].get() : nullptr, ws.J[par][0].get(), CPLX ? ws.J[par][1].get() : nullptr,
@@ -1347,7 +1361,7 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
       } else {
         // ONE launch: tile solves of round r+1 (assembled from this round's G, J, D) + the whole update of round r
         const int next_slot = (r == rounds - 1) ? sweep + 1 : sweep;
-        hipLaunchKernelGGL((jacobi_fused_round_kernel<NT, CPLX>), dim3(fused_grid), dim3(256), 0, st,
+        hipLaunchKernelGGL((jacobi_fused_round_kernel<NT, CPLX>), dim3(fused_grid), dim3(jac_threads<NT>()), 0, st,
                            ws.G[cur][0].get(), CPLX ? ws.G[cur][1].get() : nullptr, ws.G[cur ^ 1][0].get(),
                            CPLX ? ws.G[cur ^ 1][1].get() : nullptr, ws.Z[cur][0].get(), CPLX ? ws.Z[cur][1].get() : nullptr,
                            ws.Z[cur ^ 1][0].get(), CPLX ? ws.Z[cur ^ 1][1].get() : nullptr, ws.J[par][0].get(),
