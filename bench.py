@@ -63,10 +63,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     td = None
+    # XMCA_BENCH_BACKEND=gloo (+ XMCA_BENCH_SHARE_GPU=1: every rank on GPU 0) exercises the multi-rank flow on a 1-GPU box
+    backend = os.environ.get("XMCA_BENCH_BACKEND", "nccl")
+    if os.environ.get("XMCA_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     if world > 1:
         import torch.distributed as td
         torch.cuda.set_device(local_rank)
-        td.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            td.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            td.init_process_group(backend=backend)
+    comm_dev = "cuda" if backend == "nccl" else "cpu"
 
     from xmca_amd import _hip
     from xmca_amd.array import MCA
@@ -97,7 +105,7 @@ def main():
     stages = {k: v / args.steps for k, v in h.timings().items()}
     stages["eigh_info"] = h.solve_info()[0]
     if td is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         td.all_reduce(tt, op=td.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = 1e3 * elapsed / args.steps
