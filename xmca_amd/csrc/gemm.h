@@ -350,19 +350,19 @@ void gemm(hipStream_t st, GemmWorkspace& ws, const TI* A, int64_t lda, const TI*
   const int nkt = ceil_div(K, GEMM_BK);
   int splits = o.force_splits;
   if (splits <= 0) {
-    // Cost model in units of one k-tile of one workgroup round (two workgroups share a CU -> 512 slots):
-    //   rounds(s) * (k-tiles per slice + ~6 tiles of prologue/epilogue) + s * (partial-sum traffic of one slice).
-    // Picks the slice count that fills whole rounds of the chip (a 276-tile Gram at 6 slices wastes 19 % in its
-    // last round, at 5 slices 10 %) without drowning in partial sums; slices stay <= 16k products deep so the
-    // panels of concurrently running tiles stay cache resident.
+    // Cost model in units of one k-tile of one workgroup (two workgroups share a CU -> 512 slots), fitted to a sweep of
+    // the split count on the C2 Gram shape (scripts/gram_splits.py: 3 -> 2.13 ms, 5 -> 1.85, 7 -> 1.74, 9 -> 1.72,
+    // 14 -> 1.79):  (tiles * s / 512 + 1/2) rounds - the last, partly filled round costs about half a round because its
+    // workgroups meet less contention - times (k-tiles per slice + ~3 tiles of prologue/epilogue), plus the partial-sum
+    // traffic of s slices.
     splits = 1;
     if (nkt >= 32) {
       const int max_s = std::min(std::max(nkt / 8, 1), 128);
       const int min_s = std::min(ceil_div(nkt, 512), max_s);
       double best = 1e300;
       for (int s_ = std::max(min_s, 1); s_ <= max_s; ++s_) {
-        const double rounds = std::ceil((double)tiles * s_ / 512.0);
-        const double cost = rounds * ((double)nkt / s_ + 6.0) * 2.0 + (s_ > 1 ? s_ * (double)tiles / 35.0 : 0.0);
+        const double rounds = std::max((double)tiles * s_ / 512.0, 1.0) + 0.5;
+        const double cost = rounds * ((double)nkt / s_ + 3.0) + (s_ > 1 ? s_ * (double)tiles / 200.0 : 0.0);
         if (cost < best) { best = cost; splits = s_; }
       }
     }
