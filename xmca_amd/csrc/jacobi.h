@@ -122,7 +122,7 @@ struct JacTileSmem {
   double Vr[NT][NT + 1];
   double Mi[CPLX ? NT : 1][CPLX ? NT + 1 : 1];
   double Vi[CPLX ? NT : 1][CPLX ? NT + 1 : 1];
-  double rc[NT / 2], rsr[NT / 2], rsi[NT / 2];
+  double sub[(NT == 64 && !CPLX) ? 4 : 1][16][17];   // two-level cross sweep: accumulated rotations of the four sub-tiles
   double red[8];
   int flag;
 };
@@ -132,13 +132,132 @@ struct JacUpdSmem {
   double Ai[CPLX ? NT : 1][CPLX ? NT + 1 : 1], Bi[CPLX ? NT : 1][CPLX ? NT + 1 : 1];
 };
 
+// ---------------------------------------------------------------------------------------------------------------
+// Two-level form of the cross-block sweep of a 64 x 64 real tile (512 threads).  The rotation steps of the flat sweep
+// are a serial chain of 32 steps, each a full pass over M and V in LDS with two workgroup barriers.  Here the 32 x 32
+// cross pairs are visited as 4 x 4 pairs of 8-index sub-blocks, four disjoint pairs at a time (sub-round r pairs
+// sub-block i of the first half with sub-block (i + r) % 4 of the second).  A sub-round:
+//   1. waves 0..3 each sweep ONE 16 x 16 sub-tile (8 steps of 8 rotations, one lane per 2 x 2 block, wave-synchronous:
+//      no workgroup barrier) in place in M, accumulate its rotations in sub[w] (16 x 16) and put the original entries
+//      back;
+//   2. all waves apply the four 16 x 16 orthogonal factors to the rows, then to the columns of M and to the columns of
+//      V as v_mfma_f64_16x16x4_f64 products on gathered rows / columns (24 MFMAs per wave).
+// Every cross pair is rotated exactly once per visit, as in the flat sweep (same convergence: 12 sweeps either way in
+// the numpy model of the ordering); the chain per tile visit drops from 32 x ~3.6k to 4 x ~7k cycles.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void jacobi_cross_sweep_twolevel(JacTileSmem<64, false>& sm, const double tol, const double abs_floor) {
+  constexpr int H = 32, SB = 8;
+  auto& Mr = sm.Mr;
+  auto& Vr = sm.Vr;
+  auto& sub = sm.sub;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+  const double floor2 = abs_floor * abs_floor, tol2 = tol * tol;
+  for (int r = 0; r < 4; ++r) {
+    // tile index of entry a (0..15) of sub-tile w
+    auto tix = [r](const int w, const int a) { return a < SB ? SB * w + a : H + SB * ((w + r) & 3) + (a - SB); };
+    if (wave < 4) {
+      const int w = wave, k1 = lane >> 3, k2 = lane & 7;
+      double bak[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = lane + 64 * q;
+        sub[w][e >> 4][e & 15] = ((e >> 4) == (e & 15)) ? 1.0 : 0.0;
+        bak[q] = Mr[tix(w, e >> 4)][tix(w, e & 15)];
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (int t = 0; t < SB; ++t) {
+        const int a_p2 = k2, a_q2 = SB + ((k2 + t) & 7), a_p1 = k1, a_q1 = SB + ((k1 + t) & 7);
+        const int p2 = tix(w, a_p2), q2 = tix(w, a_q2), p1 = tix(w, a_p1), q1 = tix(w, a_q1);
+        // rotation of pair k2 (every lane; lane l < 8 holds the rotation of pair l)
+        double c2, s2;
+        {
+          const double app = Mr[p2][p2], aqq = Mr[q2][q2], g = Mr[p2][q2];
+          const double g2 = g * g;
+          const bool rot = g2 > floor2 && g2 > tol2 * fabs(app * aqq);
+          const double d = aqq - app;
+          const double x = rot ? d * d + 4.0 * g2 : 1.0;
+          const double inv = jac_rcp(fabs(d) + x * jac_rsqrt(x));
+          const double wt = (d >= 0.0 ? 2.0 : -2.0) * inv;       // t / |g|
+          const double c = jac_rsqrt(1.0 + (rot ? wt * wt * g2 : 0.0));
+          c2 = rot ? c : 1.0;
+          s2 = rot ? wt * c * g : 0.0;
+        }
+        const double c1 = __shfl(c2, k1), s1 = __shfl(s2, k1);
+        const double b00 = Mr[p1][p2], b01 = Mr[p1][q2], b10 = Mr[q1][p2], b11 = Mr[q1][q2];
+        const int jr = lane >> 3;                                   // rows jr and jr + 8 of the accumulated factor
+        const double j0p = sub[w][jr][a_p2], j0q = sub[w][jr][a_q2], j1p = sub[w][jr + 8][a_p2], j1q = sub[w][jr + 8][a_q2];
+        // rows: x0 = c1 b0 - s1 b1 ; x1 = s1 b0 + c1 b1 ; cols: y_i0 = c2 x_i0 - s2 x_i1 ; y_i1 = s2 x_i0 + c2 x_i1
+        const double x00 = c1 * b00 - s1 * b10, x01 = c1 * b01 - s1 * b11;
+        const double x10 = s1 * b00 + c1 * b10, x11 = s1 * b01 + c1 * b11;
+        double y00 = c2 * x00 - s2 * x01, y01 = s2 * x00 + c2 * x01;
+        double y10 = c2 * x10 - s2 * x11, y11 = s2 * x10 + c2 * x11;
+        if (k1 == k2) { y01 = 0.0; y10 = 0.0; }
+        __builtin_amdgcn_wave_barrier();                            // (a wave issues one instruction for all lanes: reads above, writes below)
+        Mr[p1][p2] = y00; Mr[p1][q2] = y01; Mr[q1][p2] = y10; Mr[q1][q2] = y11;
+        sub[w][jr][a_p2] = c2 * j0p - s2 * j0q;
+        sub[w][jr][a_q2] = s2 * j0p + c2 * j0q;
+        sub[w][jr + 8][a_p2] = c2 * j1p - s2 * j1q;
+        sub[w][jr + 8][a_q2] = s2 * j1p + c2 * j1q;
+        __builtin_amdgcn_wave_barrier();
+      }
+      // the working copy goes back to what it was: the products below transform whole rows and columns
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = lane + 64 * q;
+        Mr[tix(w, e >> 4)][tix(w, e & 15)] = bak[q];
+      }
+    }
+    __syncthreads();
+    // rows: M[idx_w, ct] <- Js_w^T M[idx_w, ct]   (set w = wave / 2, column tiles 2 (wave % 2) + {0, 1})
+    {
+      const int w = wave >> 1;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int ct = 2 * (wave & 1) + u;
+        d4_t acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int k = 4 * kk + l4;
+          acc = Mfma<double>::mma(sub[w][k][l15], Mr[tix(w, k)][ct * 16 + l15], acc);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Mr[tix(w, l4 + 4 * q)][ct * 16 + l15] = acc[q];
+      }
+    }
+    __syncthreads();
+    // columns: X[rt, idx_w] <- X[rt, idx_w] Js_w for X = M and V   (set w = wave / 2, row tiles 2 (wave % 2) + {0, 1})
+    {
+      const int w = wave >> 1;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int rt = 2 * (wave & 1) + u;
+        d4_t am = {0, 0, 0, 0}, av = {0, 0, 0, 0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int k = 4 * kk + l4;
+          const double js = sub[w][k][l15];
+          am = Mfma<double>::mma(Mr[rt * 16 + l15][tix(w, k)], js, am);
+          av = Mfma<double>::mma(Vr[rt * 16 + l15][tix(w, k)], js, av);
+        }
+        const int col = tix(w, l15);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          Mr[rt * 16 + l4 + 4 * q][col] = am[q];
+          Vr[rt * 16 + l4 + 4 * q][col] = av[q];
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 template <int NT, bool CPLX, bool PRELOADED = false>
 __device__ __forceinline__ void jacobi_tile_evd_body(JacTileSmem<NT, CPLX>& sm, const int P, const double* __restrict__ Gr,
                                                      const double* __restrict__ Gi, int ld, double* __restrict__ Jr,
                                                      double* __restrict__ Ji, double* __restrict__ Dr, double* __restrict__ Di,
                                                      double tol, const double* __restrict__ scal,
                                                      unsigned long long* __restrict__ sweep_off, int max_sweeps,
-                                                     const bool cross_only) {
+                                                     const bool cross_only, const bool twolevel = false) {
   constexpr int THR = jac_threads<NT>();
   constexpr int NW = THR / 64;
   constexpr int H = NT / 2;
@@ -147,9 +266,6 @@ __device__ __forceinline__ void jacobi_tile_evd_body(JacTileSmem<NT, CPLX>& sm, 
   auto& Mi = sm.Mi;
   auto& Vr = sm.Vr;
   auto& Vi = sm.Vi;
-  auto& rc = sm.rc;
-  auto& rsr = sm.rsr;
-  auto& rsi = sm.rsi;
   auto& red = sm.red;
   int& flag = sm.flag;
 
@@ -369,8 +485,19 @@ __device__ __forceinline__ void jacobi_tile_evd_body(JacTileSmem<NT, CPLX>& sm, 
   }
 
   };
-  if (cross_only) run_sweeps(std::true_type{});
-  else run_sweeps(std::false_type{});
+  if constexpr (NT == 64 && !CPLX && jac_threads<NT>() == 512) {
+    static_assert(sizeof(sm.sub) >= sizeof(double) * 4 * 16 * 17, "");
+    if (cross_only && max_sweeps == 1 && twolevel) {
+      jacobi_cross_sweep_twolevel(sm, tol, abs_floor);
+    } else if (cross_only) {
+      run_sweeps(std::true_type{});
+    } else {
+      run_sweeps(std::false_type{});
+    }
+  } else {
+    if (cross_only) run_sweeps(std::true_type{});
+    else run_sweeps(std::false_type{});
+  }
 
 #ifdef XMCA_JAC_PROF
   if (PRELOADED && tid == 0) jac_prof[((int)blockIdx.x * JAC_PROF_IT) * JAC_PROF_ST + 6] = (long long)__builtin_readcyclecounter();
@@ -782,7 +909,7 @@ __global__ __launch_bounds__(jac_threads<NT>(), 2 * jac_threads<NT>() / 256) voi
                                                                  double* Dr, double* Di, double tol, const double* scal,
                                                                  unsigned long long* sweep_off, int max_sweeps, int cross_only) {
   __shared__ JacTileSmem<NT, CPLX> sm;
-  jacobi_tile_evd_body<NT, CPLX>(sm, blockIdx.x, Gr, Gi, ld, Jr, Ji, Dr, Di, tol, scal, sweep_off, max_sweeps, cross_only != 0);
+  jacobi_tile_evd_body<NT, CPLX>(sm, blockIdx.x, Gr, Gi, ld, Jr, Ji, Dr, Di, tol, scal, sweep_off, max_sweeps, (cross_only & 1) != 0, (cross_only & 2) != 0);
 }
 
 template <int NT, bool CPLX>
@@ -1173,7 +1300,7 @@ __global__ __launch_bounds__(jac_threads<NT>(), jacobi_fused_wgs_per_cu<NT>() * 
     if (threadIdx.x == 0) jac_prof[(int)blockIdx.x * JAC_PROF_IT * JAC_PROF_ST + 0] = (long long)__builtin_readcyclecounter();
 #endif
     jacobi_tile_evd_body<NT, CPLX, true>(sm.t, blockIdx.x, nullptr, nullptr, ld, Jr_next, Ji_next, Dr_next, Di_next, tol, scal,
-                                         sweep_off, max_sweeps, cross_only != 0);
+                                         sweep_off, max_sweeps, (cross_only & 1) != 0, (cross_only & 2) != 0);
     __syncthreads();     // the tile image is dead; this workgroup now helps with what is left of the update
 #ifdef XMCA_JAC_PROF
     if (threadIdx.x == 0) jac_prof[(int)blockIdx.x * JAC_PROF_IT * JAC_PROF_ST + 1] = (long long)__builtin_readcyclecounter();
@@ -1306,6 +1433,9 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
   // tiles are swept in full once per outer sweep (its first round), cross-block only otherwise
   static const bool cross_on = [] { const char* e = std::getenv("XMCA_JACOBI_CROSS"); return !(e && e[0] == '0'); }();
   auto is_cross = [&](int round_in_sweep) { return cross_on && S > 1 && inner_cap == 1 && round_in_sweep != 0; };
+  // bit 1: two-level form of the cross sweep (64 x 64 real tiles; XMCA_JACOBI_TWOLEVEL=0 selects the flat sweep)
+  static const bool twolevel_on = [] { const char* e = std::getenv("XMCA_JACOBI_TWOLEVEL"); return !(e && e[0] == '0'); }();
+  const int cross_code = twolevel_on ? 3 : 1;
   auto evd = [&](hipStream_t s, int gbuf, int par, int sweep_slot, int round_in_sweep) {
     hipLaunchKernelGGL((jacobi_tile_evd_kernel<NT, CPLX>), dim3(S), dim3(jac_threads<NT>()), 0, s, ws.G[gbuf][0].get(),
                        CPLX ? ws.G[gbuf][1].get() : nullptr, npad, ws.J[par][0].get(), CPLX ? ws.J[par][1].get() : nullptr,
@@ -1368,7 +1498,7 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
                            CPLX ? ws.J[par][1].get() : nullptr, ws.D[par][0].get(), CPLX ? ws.D[par][1].get() : nullptr,
                            ws.J[par ^ 1][0].get(), CPLX ? ws.J[par ^ 1][1].get() : nullptr, ws.D[par ^ 1][0].get(),
                            CPLX ? ws.D[par ^ 1][1].get() : nullptr, tile_tol, ws.scal.get(), ws.off.get() + next_slot,
-                           inner_cap, is_cross((r + 1) % rounds) ? 1 : 0, S, npad, ws.work.get() + round_no, zch2, n_static,
+                           inner_cap, is_cross((r + 1) % rounds) ? cross_code : 0, S, npad, ws.work.get() + round_no, zch2, n_static,
                            exile_ncu);
       }
 #ifdef XMCA_JAC_PROF
