@@ -1051,7 +1051,9 @@ __device__ __forceinline__ void jacobi_persistent_update(JacUpdSmem<NT, CPLX>& s
 #pragma unroll
     for (int a = 0; a < NACC; ++a) {
       const int t = wave * NACC + a, ti = t / TPD, tj = t % TPD;
-      d4_t ar = {0, 0, 0, 0}, ai = {0, 0, 0, 0};
+      // complex: three real products instead of four (the f64 matrix pipe is the bound of the update):
+      //   (a - ib)(c + id):  k1 = ac, k2 = bd, k3 = (a + b)(d - c)  ->  Re = k1 + k2,  Im = k3 + k1 - k2
+      d4_t ar = {0, 0, 0, 0}, ai = {0, 0, 0, 0}, a3 = {0, 0, 0, 0};
 #pragma unroll 4
       for (int k0 = 0; k0 < NT; k0 += 4) {
         const int k = k0 + l4;
@@ -1061,13 +1063,16 @@ __device__ __forceinline__ void jacobi_persistent_update(JacUpdSmem<NT, CPLX>& s
         if constexpr (CPLX) {
           const double ji = Ai[k][ti * 16 + l15];
           const double tim = Bi[k][tj * 16 + l15];
-          ar = Mfma<double>::mma(ji, tim, ar);
-          ai = Mfma<double>::mma(jr, tim, ai);
-          ai = Mfma<double>::mma(-ji, tr, ai);
+          ai = Mfma<double>::mma(ji, tim, ai);
+          a3 = Mfma<double>::mma(jr + ji, tim - tr, a3);
         }
       }
-      xr[a] = ar;
-      if constexpr (CPLX) xi[a] = ai;
+      if constexpr (CPLX) {
+        xr[a] = ar + ai;
+        xi[a] = a3 + ar - ai;
+      } else {
+        xr[a] = ar;
+      }
     }
     __syncthreads();
 #pragma unroll
@@ -1087,7 +1092,8 @@ __device__ __forceinline__ void jacobi_persistent_update(JacUpdSmem<NT, CPLX>& s
 #pragma unroll
     for (int a = 0; a < NACC; ++a) {
       const int t = wave * NACC + a, ti = t / TPD, tj = t % TPD;
-      d4_t ar = {0, 0, 0, 0}, ai = {0, 0, 0, 0};
+      //   (a + ib)(c + id):  k1 = ac, k2 = bd, k3 = (a + b)(c + d)  ->  Re = k1 - k2,  Im = k3 - k1 - k2
+      d4_t ar = {0, 0, 0, 0}, ai = {0, 0, 0, 0}, a3 = {0, 0, 0, 0};
 #pragma unroll 4
       for (int k0 = 0; k0 < NT; k0 += 4) {
         const int k = k0 + l4;
@@ -1097,13 +1103,16 @@ __device__ __forceinline__ void jacobi_persistent_update(JacUpdSmem<NT, CPLX>& s
         if constexpr (CPLX) {
           const double xim = Bi[ti * 16 + l15][k];
           const double qi = Ai[k][tj * 16 + l15];
-          ar = Mfma<double>::mma(-xim, qi, ar);
-          ai = Mfma<double>::mma(xre, qi, ai);
-          ai = Mfma<double>::mma(xim, qr, ai);
+          ai = Mfma<double>::mma(xim, qi, ai);
+          a3 = Mfma<double>::mma(xre + xim, qr + qi, a3);
         }
       }
-      yr[a] = ar;
-      if constexpr (CPLX) yi[a] = ai;
+      if constexpr (CPLX) {
+        yr[a] = ar - ai;
+        yi[a] = a3 - ar - ai;
+      } else {
+        yr[a] = ar;
+      }
     }
     __syncthreads();
 #pragma unroll
