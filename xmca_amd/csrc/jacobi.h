@@ -940,9 +940,14 @@ __device__ __forceinline__ JacItem jacobi_decode_item(int id, const int S, const
   if (id < 0) return it;
   if (id < n_off) {
     it.kind = 1;
-    int P = 0, rem = id;
-    while (rem >= S - 1 - P) { rem -= S - 1 - P; ++P; }
-    it.P = P; it.Q = P + 1 + rem;
+    // row P of the strictly upper triangle starts at off(P) = P (2S - P - 1) / 2: closed form + fix-up (a search loop
+    // here costs a few hundred cycles per item on the scalar unit)
+    const int b = 2 * S - 1;
+    int P = (int)(0.5f * ((float)b - sqrtf((float)(b * b - 8 * id))));
+    P = max(0, min(P, S - 2));
+    while (P > 0 && id < P * (2 * S - P - 1) / 2) --P;
+    while (id >= (P + 1) * (2 * S - P - 2) / 2) ++P;
+    it.P = P; it.Q = P + 1 + (id - P * (2 * S - P - 1) / 2);
     return it;
   }
   id -= n_off;
