@@ -80,6 +80,14 @@ int xmca_get_vectors(xmca_handle* h, int side, void* out, int64_t n_modes, int d
  * The scaling by 1/sqrt(sigma) and the rotation (array.py:391-393) stay with the caller (m x m work). */
 int xmca_project(xmca_handle* h, int side, const void* V, int64_t N, int64_t m, int is_complex, void* U_out,
                  int* out_is_complex);
+
+/* Correlation maps of MCA.homogeneous_patterns / heterogeneous_patterns (xmca/array.py:1188-1261, the Pearson
+ * correlation of tools/array.py:76-88): r[n][j] = corr(real part of field column n of `side`, Y[:, j]) on the resident
+ * field - one tall GEMM X^T Y plus column moments instead of the reference's (N + m)^2 corrcoef matrix.
+ *   Y      T x m row-major float64 (the real parts of the PCs), host memory
+ *   r_out  N x m row-major float64
+ * p-values (scipy.stats.beta) stay with the caller. */
+int xmca_correlate(xmca_handle* h, int side, const double* Y, int64_t T, int64_t m, double* r_out);
 int xmca_is_complex(xmca_handle* h);
 /* Diagnostics of the last solve: for each of the up to three eigen-decompositions (left Gram, right Gram, kernel):
  * info[3*i + 0] = outer sweeps, info[3*i + 1] = tile size, info[3*i + 2] = pair slots.  n <= 9. */

@@ -304,3 +304,30 @@ def test_pcs_projection_after_the_handle_was_used_elsewhere():
     for key in a._keys:
         ref = ((X[key] @ a._V[key][:, :6] / np.sqrt(a._singular_values[:6])) @ R)[:, a._var_idx]
         assert _rel(first[key], ref) < 1e-9
+
+
+# ----------------------------------------------------------------------------------------------
+# correlation maps on the device (homogeneous / heterogeneous patterns, array.py:1188-1261)
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,cplx", [("sst_prcp", False), ("sst_prcp", True), ("wide_both", False), ("wide_both_f32", True)])
+def test_correlation_maps_match_pearsonr(name, cplx):
+    """r = corr(real field, real PCs) as a device GEMM + column moments; the reference forms np.corrcoef of all N + m
+    columns (tools/array.py:76-88).  NaN columns come back as NaN, p-values from the same beta distribution."""
+    from xmca_amd.tools.array import pearsonr
+    m = MCA(*make_input(name))
+    m.solve(complexify=cplx)
+    m.rotate(6, 2)
+    X = m._get_X(real=True)
+    pcs = m.pcs(6)
+    other = {'left': 'right', 'right': 'left'}
+    for maps, pair in ((m.homogeneous_patterns(6), {k: k for k in m._keys}), (m.heterogeneous_patterns(6), other)):
+        rv, pv = maps
+        for k in m._keys:
+            r_ref, p_ref = pearsonr(X[k], pcs[pair[k]].real)
+            valid = m._no_nan_index[k]
+            r = rv[k].reshape(-1, 6)
+            p = pv[k].reshape(-1, 6)
+            tol = 2e-5 if X[k].dtype == np.float32 else 1e-10
+            assert np.all(np.isnan(r[~valid])) and np.all(np.isnan(p[~valid]))
+            assert np.max(np.abs(r[valid] - r_ref)) < tol
+            assert np.max(np.abs(p[valid] - p_ref)) < 50 * tol

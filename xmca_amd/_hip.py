@@ -35,6 +35,7 @@ SIGNATURES = {
     "xmca_solve": (_c_int, [_vp, _c_int, _c_i64, ctypes.POINTER(_c_i64)]),
     "xmca_get_singular_values": (_c_int, [_vp, _vp, _c_i64]),
     "xmca_get_vectors": (_c_int, [_vp, _c_int, _vp, _c_i64, _c_int]),
+    "xmca_correlate": (_c_int, [_vp, _c_int, _vp, _c_i64, _c_i64, _vp]),
     "xmca_project": (_c_int, [_vp, _c_int, _vp, _c_i64, _c_i64, _c_int, _vp, ctypes.POINTER(_c_int)]),
     "xmca_is_complex": (_c_int, [_vp]),
     "xmca_get_solve_info": (_c_int, [_vp, _vp, _c_int]),
@@ -231,6 +232,15 @@ class Handle:
         if out_cplx.value:
             return out
         return out.view(np.float64).reshape(-1)[:T * m].reshape(T, m).copy()
+
+    def correlate(self, side, Y, N):
+        """r (N x m) = Pearson correlation of the real part of every column of the resident field `side` with the columns
+        of Y (T x m).  tools/array.py:76-88 without the (N + m)^2 corrcoef matrix."""
+        Yd = np.ascontiguousarray(np.asarray(Y).real, dtype=np.float64)
+        T, m = Yd.shape
+        r = np.empty((N, m), dtype=np.float64)
+        self._check(self._lib.xmca_correlate(self._h, side, _ptr(Yd), T, m, _ptr(r)))
+        return r
 
     # ---- rotation -----------------------------------------------------------------------------
     def rotate_loadings(self, L, n_left, power=1, tol=1e-8, max_iter=1000, varimax_only=False, want_B=False):

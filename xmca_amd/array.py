@@ -583,14 +583,26 @@ class MCA:
                 for k, p in self.pcs(n, phase_shift=phase_shift, rotated=rotated).items()}
 
     def _correlation_maps(self, n, phase_shift, pair):
+        """Pearson correlation of every grid point (real part of the field) with the PCs and its p-value
+        (array.py:1188-1261, tools/array.py:76-88).  The correlations are one tall GEMM over the field resident on the
+        device (`xmca_correlate`) instead of the reference's (N + m)^2 `np.corrcoef` matrix; p-values on the host."""
+        import scipy.stats
         pcs = self._get_pcs(n=n, phase_shift=phase_shift)
-        Xraw = self._get_X(real=True)
+        dev = self._device()
+        if getattr(dev, 'fields_owner', None) != (id(self), self._upload_serial):
+            self._upload_serial += 1
+            self._upload_fields(dev)
+        n_obs = self._n_observations['left']
+        dist = scipy.stats.beta(n_obs / 2 - 1, n_obs / 2 - 1, loc=-1, scale=2)
         rvals, pvals = {}, {}
-        for k in self._keys:
+        for side, k in enumerate(self._keys):
             try:
-                r, p = pearsonr(Xraw[k], pcs[pair[k]].real)
+                y = pcs[pair[k]].real
             except KeyError:
                 raise KeyError('Key not found. Two fields needed for heterogenous maps.')
+            r = dev.correlate(side, y, self._fields_store[k].shape[1])
+            r = r.astype(np.result_type(self._fields_store[k].real.dtype, y.dtype), copy=False)
+            p = 2 * dist.cdf(-abs(r))
             for src, dst in ((r, rvals), (p, pvals)):
                 full = self._with_nan_columns(k, src.T, (src.shape[1],)).T
                 dst[k] = full.reshape(self._fields_spatial_shape[k] + (src.shape[1],))

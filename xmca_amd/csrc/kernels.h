@@ -137,6 +137,35 @@ __global__ void center_columns_kernel(T* __restrict__ x, int rows, int64_t cols)
   for (int r = 0; r < rows; ++r) x[(int64_t)r * cols + c] = (T)((double)x[(int64_t)r * cols + c] - m);
 }
 
+// column sums and sums of squares of a rows x cols matrix (one thread per column, coalesced over columns)
+template <typename T>
+__global__ void column_moments_kernel(const T* __restrict__ x, int rows, int64_t cols, double* __restrict__ sum,
+                                      double* __restrict__ sumsq) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  double s = 0.0, q = 0.0;
+  for (int r = 0; r < rows; ++r) {
+    const double v = (double)x[(int64_t)r * cols + c];
+    s += v;
+    q += v * v;
+  }
+  sum[c] = s;
+  sumsq[c] = q;
+}
+
+// Pearson correlation from the raw cross products: r[n][j] = (C[n][j] - sx[n] sy[j] / T) / sqrt((qx[n] - sx[n]^2 / T) (qy[j] - sy[j]^2 / T))
+__global__ void pearson_finish_kernel(double* __restrict__ C, int64_t N, int m, int T, const double* __restrict__ sx,
+                                      const double* __restrict__ qx, const double* __restrict__ sy, const double* __restrict__ qy) {
+  const int64_t total = N * m;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i / m;
+    const int j = (int)(i % m);
+    const double cov = C[i] - sx[n] * sy[j] / T;
+    const double vx = qx[n] - sx[n] * sx[n] / T, vy = qy[j] - sy[j] * sy[j] / T;
+    C[i] = cov / sqrt(vx * vy);          // constant columns give NaN, like numpy.corrcoef
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Philox4x32-10 counter-based generator (Salmon et al. 2011) -> standard normals (Box-Muller).
 // counter = (element pair index lo, hi, run, side), key = seed: the stream of a surrogate depends only on

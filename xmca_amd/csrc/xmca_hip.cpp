@@ -242,6 +242,35 @@ void project_impl(xmca_handle* h, int side, const void* V, int64_t N, int64_t m,
   *out_cplx = cplx ? 1 : 0;
 }
 
+// r = corr(Re field columns, Y columns)  (see xmca_correlate)
+template <typename TI>
+void correlate_impl(xmca_handle* h, int side, const double* Y, int64_t T, int64_t m, double* r_out) {
+  FieldData<TI>& f = fields_of<TI>(h)[side];
+  XMCA_CHECK(f.T == T, XMCA_ERR_INVALID, "correlate: Y has " + std::to_string(T) + " rows, the field has " + std::to_string(f.T));
+  const int64_t N = f.N;
+  DevBuf<double> yh, sx, qx, sy, qy, C;
+  DevBuf<TI> yt;
+  const size_t ny = (size_t)T * m;
+  XMCA_HIP(hipMemcpyAsync(yh.ensure(ny), Y, sizeof(double) * ny, hipMemcpyHostToDevice, h->st));
+  hipLaunchKernelGGL((convert_kernel<double, TI>), ew_grid((int64_t)ny), dim3(EW_BLOCK), 0, h->st, yh.get(), yt.ensure(ny), (int64_t)ny);
+  h->tm.begin("correlate");
+  hipLaunchKernelGGL((column_moments_kernel<TI>), dim3((unsigned)ceil_div(N, (int64_t)256)), dim3(256), 0, h->st, f.r(), (int)T, N,
+                     sx.ensure((size_t)N), qx.ensure((size_t)N));
+  hipLaunchKernelGGL((column_moments_kernel<double>), dim3((unsigned)ceil_div(m, (int64_t)256)), dim3(256), 0, h->st, yh.get(), (int)T,
+                     m, sy.ensure((size_t)m), qy.ensure((size_t)m));
+  XMCA_HIP(hipGetLastError());
+  // C = X^T Y   (N x m): A(n, t) = X[t * N + n], B(t, j) = Y[t * m + j]
+  GemmOpts o;
+  o.a_kfast = false;
+  gemm<TI, double>(h->st, h->gws, f.r(), N, yt.get(), m, C.ensure((size_t)N * m), m, (int)N, (int)m, (int)T, o);
+  hipLaunchKernelGGL(pearson_finish_kernel, ew_grid(N * m), dim3(EW_BLOCK), 0, h->st, C.get(), N, (int)m, (int)T, sx.get(), qx.get(),
+                     sy.get(), qy.get());
+  XMCA_HIP(hipGetLastError());
+  h->tm.end();
+  XMCA_HIP(hipMemcpyAsync(r_out, C.get(), sizeof(double) * (size_t)N * m, hipMemcpyDeviceToHost, h->st));
+  XMCA_HIP(hipStreamSynchronize(h->st));
+}
+
 void fill_rot_outputs(const RotateResult& rr, bool cplx, double* R_out, double* Phi_out, double* nl, double* nr, int* iters) {
   const int p = rr.p;
   if (iters) *iters = rr.iters;
@@ -459,6 +488,16 @@ int xmca_project(xmca_handle* h, int side, const void* V, int64_t N, int64_t m, 
   XMCA_CHECK(V && U_out && out_is_complex && N >= 1 && m >= 1, XMCA_ERR_INVALID, "project: need an N x m matrix of vectors");
   if (h->dtype == XMCA_F32) project_impl<float>(h, side, V, N, m, is_complex != 0, U_out, out_is_complex);
   else project_impl<double>(h, side, V, N, m, is_complex != 0, U_out, out_is_complex);
+  API_END(h)
+}
+
+int xmca_correlate(xmca_handle* h, int side, const double* Y, int64_t T, int64_t m, double* r_out) {
+  API_BEGIN(h)
+  XMCA_CHECK(side == 0 || side == 1, XMCA_ERR_INVALID, "correlate: side must be 0 or 1");
+  XMCA_CHECK(h->field_set[side], XMCA_ERR_STATE, "correlate: no field resident for this side");
+  XMCA_CHECK(Y && r_out && T >= 2 && m >= 1, XMCA_ERR_INVALID, "correlate: need a T x m matrix");
+  if (h->dtype == XMCA_F32) correlate_impl<float>(h, side, Y, T, m, r_out);
+  else correlate_impl<double>(h, side, Y, T, m, r_out);
   API_END(h)
 }
 
