@@ -88,6 +88,19 @@ int xmca_project(xmca_handle* h, int side, const void* V, int64_t N, int64_t m, 
  *   r_out  N x m row-major float64
  * p-values (scipy.stats.beta) stay with the caller. */
 int xmca_correlate(xmca_handle* h, int side, const double* Y, int64_t T, int64_t m, double* r_out);
+
+/* MCA.bootstrapping (xmca/array.py:1813-1952): replicates on the device.
+ * xmca_bootstrap_begin copies the real planes of the fields set with xmca_set_field (the caller's X_surr,
+ * array.py:1925-1933) into working buffers.  Each xmca_bootstrap_run then
+ *   resamples them along time, X <- X[idx, :] - cumulatively, like the reference's loop, which overwrites X_surr
+ *   (idx_left / idx_right: T row indices drawn by the caller exactly as tools/array.py:91-138 does, or NULL when that
+ *   side is not resampled),
+ *   centers a copy (the MCA constructor, array.py:117), complexifies when hilbert_col != NULL, solves, rotates
+ *   (rotated != 0: n_rot = p, power, tol) and returns the variance spectrum of `_get_variance` (array.py:755-779):
+ *   `rank` singular values, or the p sorted norm products of the rotated model; *kept_out = 0 when Varimax failed. */
+int xmca_bootstrap_begin(xmca_handle* h, int n_fields);
+int xmca_bootstrap_run(xmca_handle* h, const double* hilbert_col, const int64_t* idx_left, const int64_t* idx_right, int rotated,
+                       int p, int power, double tol, double* spectrum_out, int* kept_out, int64_t n_out);
 int xmca_is_complex(xmca_handle* h);
 /* Diagnostics of the last solve: for each of the up to three eigen-decompositions (left Gram, right Gram, kernel):
  * info[3*i + 0] = outer sweeps, info[3*i + 1] = tile size, info[3*i + 2] = pair slots.  n <= 9. */

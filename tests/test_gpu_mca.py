@@ -331,3 +331,33 @@ def test_correlation_maps_match_pearsonr(name, cplx):
             assert np.all(np.isnan(r[~valid])) and np.all(np.isnan(p[~valid]))
             assert np.max(np.abs(r[valid] - r_ref)) < tol
             assert np.max(np.abs(p[valid] - p_ref)) < 50 * tol
+
+
+# ----------------------------------------------------------------------------------------------
+# bootstrapping replicates on the device (array.py:1813-1952)
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,single,cplx,rot,kw", [
+    ("small_both", False, False, None, dict(on_left=True, on_right=True, block_size=2)),
+    ("wide_both", False, False, (5, 2), dict(on_left=True, on_right=False, block_size=1)),
+    ("wide_both", True, True, None, dict(on_left=True, on_right=False, block_size=4, replace=False)),
+    ("wide_both", False, True, (4, 1), dict(on_left=False, on_right=True, block_size=1)),
+    ("sst_prcp", False, False, None, dict(on_left=True, on_right=True, block_size=3, strategy='iterative'))])
+def test_bootstrapping_device_replicates_equal_host_loop(name, single, cplx, rot, kw):
+    """same numpy seed -> same block draws: the device replicates (cumulative row gather, centering, solve, rotate)
+    must reproduce the reference's host loop (one MCA per replicate) to rounding."""
+    fields = make_input(name)
+    if single:
+        fields = fields[:1]
+    out = {}
+    for host in (False, True):
+        m = MCA(*fields)
+        m.solve(complexify=cplx)
+        if rot:
+            m.rotate(*rot)
+        m._bootstrap_on_host = host
+        np.random.seed(5)
+        out[host] = m.bootstrapping(3, n_modes=4, **kw)
+    assert out[False].shape == out[True].shape
+    scale = np.abs(out[True]).max()
+    tol = 2e-5 if fields[0].dtype == np.float32 else 1e-8
+    assert np.max(np.abs(out[False] - out[True])) < tol * scale

@@ -35,6 +35,8 @@ SIGNATURES = {
     "xmca_solve": (_c_int, [_vp, _c_int, _c_i64, ctypes.POINTER(_c_i64)]),
     "xmca_get_singular_values": (_c_int, [_vp, _vp, _c_i64]),
     "xmca_get_vectors": (_c_int, [_vp, _c_int, _vp, _c_i64, _c_int]),
+    "xmca_bootstrap_begin": (_c_int, [_vp, _c_int]),
+    "xmca_bootstrap_run": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_dbl, _vp, ctypes.POINTER(_c_int), _c_i64]),
     "xmca_correlate": (_c_int, [_vp, _c_int, _vp, _c_i64, _c_i64, _vp]),
     "xmca_project": (_c_int, [_vp, _c_int, _vp, _c_i64, _c_i64, _c_int, _vp, ctypes.POINTER(_c_int)]),
     "xmca_is_complex": (_c_int, [_vp]),
@@ -232,6 +234,21 @@ class Handle:
         if out_cplx.value:
             return out
         return out.view(np.float64).reshape(-1)[:T * m].reshape(T, m).copy()
+
+    def bootstrap_begin(self, n_fields):
+        """Working copies of the resident fields for `bootstrap_run` (MCA.bootstrapping on the device)."""
+        self._check(self._lib.xmca_bootstrap_begin(self._h, n_fields))
+
+    def bootstrap_run(self, T, complexify, idx_left, idx_right, rotated, p, power, tol, n_out):
+        """One replicate: resample rows (cumulatively), center, solve (+ rotate).  Returns (spectrum[n_out], kept)."""
+        ht = hilbert_imag_column(T) if complexify else None
+        il = None if idx_left is None else np.ascontiguousarray(idx_left, dtype=np.int64)
+        ir = None if idx_right is None else np.ascontiguousarray(idx_right, dtype=np.int64)
+        out = np.zeros(n_out, dtype=np.float64)
+        kept = _c_int(0)
+        self._check(self._lib.xmca_bootstrap_run(self._h, _ptr(ht), _ptr(il), _ptr(ir), int(rotated), int(p), int(power), float(tol),
+                                                 _ptr(out), ctypes.byref(kept), n_out))
+        return out, bool(kept.value)
 
     def correlate(self, side, Y, N):
         """r (N x m) = Pearson correlation of the real part of every column of the resident field `side` with the columns

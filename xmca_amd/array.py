@@ -396,6 +396,8 @@ class MCA:
             self._upload_serial += 1          # another model / rule_n used the handle in between: upload again
             self._upload_fields(dev)
         T = self._n_observations['left']
+        if next(iter(V.values())).shape[1] == 0:          # pcs(0): nothing to project (bootstrapping's first iterative step)
+            return {k: np.zeros((T, 0), dtype=V[k].dtype) for k in self._keys}
         return {k: dev.project(side, V[k], T) for side, k in enumerate(self._keys)}
 
     def _get_U(self, n=None, rotated=True):
@@ -723,8 +725,10 @@ class MCA:
                       strategy='standard', disable_progress=False):
         """Monte Carlo (moving-block) bootstrap / permutation of the model (array.py:1813-1952).
 
-        Resampling happens on the host with numpy's global RNG (as in the reference); every resampled model is
-        solved (and rotated) on the device.
+        The block indices are drawn on the host from numpy's global RNG exactly as the reference draws them
+        (tools/array.py:91-138), the replicates themselves - cumulative row resampling, centering, solve, rotation,
+        variance - run on the device (`xmca_bootstrap_run`).  Column resampling (`axis=1`) and models with a
+        fore/back-cast extension keep the reference's host loop with one device solve per replicate.
         """
         complexify = self._analysis['is_complex']
         extend = self._analysis['extend']
@@ -734,12 +738,44 @@ class MCA:
         power = self._analysis['power']
         n_modes_max = self._get_min_mode(n_modes, rotated=True)
         var_surr = np.zeros([n_modes_max, n_runs])
+        on_device = axis == 0 and not extend and not getattr(self, '_bootstrap_on_host', False)
+        dev = self._device()
+        n_obs = self._n_observations['left']
         for mode in range(n_modes):
             X_surr = self._get_X(original_scale=False, real=True)
             if strategy == 'iterative':
                 X_rec = self._reconstructed_X(mode=mode, original_scale=False)
                 for k in X_surr:
                     X_surr[k] -= X_rec[k]
+            if on_device:
+                if on_right and 'right' not in X_surr:
+                    raise ValueError('No bootstrapping possible. There is no right field. Set `on_right=False`.')
+                if n_obs % block_size:
+                    raise ValueError('Length of data array ({:}) must be a multiple of block size {:}'.format(n_obs, block_size))
+                for side, k in enumerate(self._keys):
+                    dev.set_field(side, _device_ready(np.ascontiguousarray(X_surr[k])))
+                dev.bootstrap_begin(len(self._keys))
+                n_blocks = n_obs // block_size
+                rank = min([n_obs] + [X_surr[k].shape[1] for k in self._keys])
+                n_out = n_rot if is_rotated else rank
+                for run in range(n_runs):
+                    idx = {'left': None, 'right': None}
+                    if on_left or on_right:
+                        # one draw per replicate, like tools/array.py:136 (both sides share it when both are resampled)
+                        pick = np.random.choice(n_blocks, size=n_blocks, replace=replace)
+                        rows = (pick[:, None] * block_size + np.arange(block_size)[None, :]).reshape(-1)
+                        if on_left:
+                            idx['left'] = rows
+                        if on_right:
+                            idx['right'] = rows
+                    spec, kept = dev.bootstrap_run(n_obs, complexify, idx['left'], idx['right'], is_rotated, n_rot, max(power, 1),
+                                                   1e-8, n_out)
+                    if not kept:
+                        continue
+                    var_surr[mode:, run] = spec[:n_modes_max - mode]
+                if strategy == 'standard':
+                    break
+                continue
             for run in range(n_runs):
                 if on_left and not on_right:
                     X_surr['left'] = block_bootstrap(X_surr['left'], axis=axis, block_size=block_size, replace=replace)

@@ -137,6 +137,17 @@ __global__ void center_columns_kernel(T* __restrict__ x, int rows, int64_t cols)
   for (int r = 0; r < rows; ++r) x[(int64_t)r * cols + c] = (T)((double)x[(int64_t)r * cols + c] - m);
 }
 
+// out[t][:] = in[idx[t]][:]   (row resampling of a rows x cols matrix)
+template <typename T>
+__global__ void gather_rows_kernel(const T* __restrict__ in, T* __restrict__ out, const int64_t* __restrict__ idx, int rows,
+                                   int64_t cols) {
+  const int64_t total = (int64_t)rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = i / cols, c = i % cols;
+    out[i] = in[idx[t] * cols + c];
+  }
+}
+
 // column sums and sums of squares of a rows x cols matrix (one thread per column, coalesced over columns)
 template <typename T>
 __global__ void column_moments_kernel(const T* __restrict__ x, int rows, int64_t cols, double* __restrict__ sum,

@@ -25,6 +25,14 @@ struct xmca_handle {
   bool hilbert_pending = false;          // complexify requested; carried out (or folded into the solve) lazily
   std::vector<double> hilbert_col;
   RotationDevice rot;
+  // bootstrapping (xmca_bootstrap_begin / _run): cumulative resampled copies of the fields, a gather target and the
+  // centered copies that are solved
+  DevBuf<float> boot32[2], boot32_tmp;
+  DevBuf<double> boot64[2], boot64_tmp;
+  FieldData<float> bootf32[2];
+  FieldData<double> bootf64[2];
+  int64_t boot_T = 0, boot_N[2] = {0, 0};
+  int boot_fields = 0;
 };
 
 #define API_BEGIN(h)                                                   \
@@ -295,49 +303,48 @@ void check_rot(const RotateResult& rr) {
              "Rotation process did not converge. Try decreasing the tolerance. Invalid NaN entries also might be a problem.");
 }
 
+// One surrogate / bootstrap replicate from centered real fields resident in `f` (re planes): complexify, solve, rotate,
+// variance spectrum (the body of the loops array.py:1753-1765 and :1935-1947).
 template <typename TI>
-void rule_n_impl(xmca_handle* h, int64_t T, int64_t Nx, int64_t Ny, int n_fields, const double* ht_host, int rotated, int p,
-                 int power, double tol, int64_t run_begin, int64_t run_end, uint64_t seed, double* spectra, int* kept,
-                 int64_t n_out) {
-  FieldData<TI> f[2];
-  const int64_t Ns[2] = {Nx, Ny};
+struct ReplicateRunner {
+  xmca_handle* h;
+  int64_t T, Ns[2];
+  int n_fields, rotated, p, power;
+  double tol;
+  bool cplx, analytic;
   DevBuf<TI> htb;
-  const bool cplx = ht_host != nullptr;
-  static const bool analytic_on = [] { const char* e = std::getenv("XMCA_ANALYTIC"); return !(e && e[0] == '0'); }();
-  const bool analytic = cplx && analytic_on && Nx > T && (n_fields == 1 || Ny > T);
-  if (cplx && !analytic) build_hilbert<TI>(h, ht_host, T, htb);
-  struct { const TI* r; } ht{htb.get()};
-  Solver<TI> solver(h->st, h->gws, h->ews, h->tm);
-  Rotator rot(h->st, h->tm);
+  Solver<TI> solver;
+  Rotator rot;
   SolveResult res;
   RotationDevice rd;
   DevBuf<double> sigma_dev;
-  const int64_t rank = std::min(T, n_fields == 2 ? std::min(Nx, Ny) : Nx);
-  XMCA_CHECK(n_out == (rotated ? (int64_t)p : rank), XMCA_ERR_INVALID, "rule_n: n_out must be rank (unrotated) or p (rotated)");
-  for (int64_t run = run_begin; run < run_end; ++run) {
-    h->tm.begin("surrogate");
+
+  ReplicateRunner(xmca_handle* h_, int64_t T_, int64_t Nx, int64_t Ny, int n_fields_, const double* ht_host, int rotated_, int p_,
+                  int power_, double tol_)
+      : h(h_), T(T_), Ns{Nx, Ny}, n_fields(n_fields_), rotated(rotated_), p(p_), power(power_), tol(tol_), cplx(ht_host != nullptr),
+        solver(h_->st, h_->gws, h_->ews, h_->tm), rot(h_->st, h_->tm) {
+    static const bool analytic_on = [] { const char* e = std::getenv("XMCA_ANALYTIC"); return !(e && e[0] == '0'); }();
+    analytic = cplx && analytic_on && Nx > T && (n_fields == 1 || Ny > T);
+    if (cplx && !analytic) build_hilbert<TI>(h, ht_host, T, htb);
+  }
+  int64_t rank() const { return std::min(T, n_fields == 2 ? std::min(Ns[0], Ns[1]) : Ns[0]); }
+
+  // f[s].re holds the centered field; returns 1 (kept) or 0 (Varimax failed: the replicate is dropped, array.py:1762-1763)
+  int run(FieldData<TI>* f, double* out, int64_t n_out) {
     for (int s = 0; s < n_fields; ++s) {
-      f[s].T = T; f[s].N = Ns[s]; f[s].has_im = false;
-      const int64_t n = T * Ns[s];
-      TI* x = f[s].re.ensure((size_t)n);
-      hipLaunchKernelGGL((philox_normal_kernel<TI>), ew_grid((n + 1) / 2), dim3(EW_BLOCK), 0, h->st, x, n, seed, (uint32_t)run,
-                         (uint32_t)s);
-      hipLaunchKernelGGL((center_columns_kernel<TI>), dim3(ceil_div(Ns[s], 256)), dim3(256), 0, h->st, x, (int)T, Ns[s]);
-      XMCA_HIP(hipGetLastError());
+      f[s].has_im = false;
       if (cplx && !analytic) {
         GemmOpts o;
-        gemm<TI, TI>(h->st, h->gws, ht.r, T, x, Ns[s], f[s].im.ensure((size_t)n), Ns[s], (int)T, (int)Ns[s], (int)T, o);
+        gemm<TI, TI>(h->st, h->gws, htb.get(), T, f[s].r(), Ns[s], f[s].im.ensure((size_t)(T * Ns[s])), Ns[s], (int)T, (int)Ns[s], (int)T, o);
         f[s].has_im = true;
+        f[s].ext_im = nullptr;
       }
     }
-    h->tm.end();
     if (analytic) solver.solve_analytic(f, n_fields, rotated ? p : 0, res);
     else solver.solve(f, n_fields, cplx, rotated ? p : 0, res);
-    double* out = spectra + (run - run_begin) * n_out;
-    kept[run - run_begin] = 1;
     if (!rotated) {
       for (int64_t i = 0; i < n_out; ++i) out[i] = res.sigma[i];
-      continue;
+      return 1;
     }
     // rotate the first p modes (array.py:815-833)
     const int64_t Nl = Ns[0], Nr = n_fields == 2 ? Ns[1] : 0;
@@ -357,15 +364,99 @@ void rule_n_impl(xmca_handle* h, int64_t T, int64_t Nx, int64_t Ny, int n_fields
       rot.run<false>(rd, power, tol, 1000, rr, nullptr, false);
     }
     if (rr.nan || !rr.converged) {       // array.py:1762-1763: the run is silently dropped
-      kept[run - run_begin] = 0;
       for (int64_t i = 0; i < n_out; ++i) out[i] = 0.0;
-      continue;
+      return 0;
     }
     std::vector<double> var(p);
     for (int k = 0; k < p; ++k) var[k] = n_fields == 2 ? rr.norm_left[k] * rr.norm_right[k] : rr.norm_left[k] * rr.norm_left[k];
     std::sort(var.begin(), var.end(), [](double a, double b) { return a > b; });
     for (int k = 0; k < p; ++k) out[k] = var[k];
+    return 1;
   }
+};
+
+template <typename TI>
+void rule_n_impl(xmca_handle* h, int64_t T, int64_t Nx, int64_t Ny, int n_fields, const double* ht_host, int rotated, int p,
+                 int power, double tol, int64_t run_begin, int64_t run_end, uint64_t seed, double* spectra, int* kept,
+                 int64_t n_out) {
+  FieldData<TI> f[2];
+  const int64_t Ns[2] = {Nx, Ny};
+  ReplicateRunner<TI> runner(h, T, Nx, Ny, n_fields, ht_host, rotated, p, power, tol);
+  XMCA_CHECK(n_out == (rotated ? (int64_t)p : runner.rank()), XMCA_ERR_INVALID, "rule_n: n_out must be rank (unrotated) or p (rotated)");
+  for (int64_t run = run_begin; run < run_end; ++run) {
+    h->tm.begin("surrogate");
+    for (int s = 0; s < n_fields; ++s) {
+      f[s].T = T; f[s].N = Ns[s]; f[s].has_im = false;
+      const int64_t n = T * Ns[s];
+      TI* x = f[s].re.ensure((size_t)n);
+      hipLaunchKernelGGL((philox_normal_kernel<TI>), ew_grid((n + 1) / 2), dim3(EW_BLOCK), 0, h->st, x, n, seed, (uint32_t)run,
+                         (uint32_t)s);
+      hipLaunchKernelGGL((center_columns_kernel<TI>), dim3(ceil_div(Ns[s], 256)), dim3(256), 0, h->st, x, (int)T, Ns[s]);
+      XMCA_HIP(hipGetLastError());
+    }
+    h->tm.end();
+    kept[run - run_begin] = runner.run(f, spectra + (run - run_begin) * n_out, n_out);
+  }
+}
+
+// ---- bootstrapping: working copies on the device -----------------------------------------------------------------
+template <typename TI> DevBuf<TI>* boot_w(xmca_handle* h);
+template <> DevBuf<float>* boot_w<float>(xmca_handle* h) { return h->boot32; }
+template <> DevBuf<double>* boot_w<double>(xmca_handle* h) { return h->boot64; }
+template <typename TI> DevBuf<TI>& boot_tmp(xmca_handle* h);
+template <> DevBuf<float>& boot_tmp<float>(xmca_handle* h) { return h->boot32_tmp; }
+template <> DevBuf<double>& boot_tmp<double>(xmca_handle* h) { return h->boot64_tmp; }
+template <typename TI> FieldData<TI>* boot_f(xmca_handle* h);
+template <> FieldData<float>* boot_f<float>(xmca_handle* h) { return h->bootf32; }
+template <> FieldData<double>* boot_f<double>(xmca_handle* h) { return h->bootf64; }
+
+template <typename TI>
+void bootstrap_begin_impl(xmca_handle* h, int n_fields) {
+  FieldData<TI>* f = fields_of<TI>(h);
+  h->boot_T = f[0].T;
+  h->boot_fields = n_fields;
+  for (int s = 0; s < n_fields; ++s) {
+    XMCA_CHECK(h->field_set[s] && f[s].T == h->boot_T, XMCA_ERR_STATE, "bootstrap: set the fields first (same number of time steps)");
+    h->boot_N[s] = f[s].N;
+    const size_t n = (size_t)f[s].T * f[s].N;
+    XMCA_HIP(hipMemcpyAsync(boot_w<TI>(h)[s].ensure(n), f[s].r(), sizeof(TI) * n, hipMemcpyDeviceToDevice, h->st));
+  }
+  XMCA_HIP(hipStreamSynchronize(h->st));
+}
+
+template <typename TI>
+void bootstrap_run_impl(xmca_handle* h, const double* ht_host, const int64_t* idx_left, const int64_t* idx_right, int rotated, int p,
+                        int power, double tol, double* spectrum, int* kept, int64_t n_out) {
+  const int n_fields = h->boot_fields;
+  const int64_t T = h->boot_T;
+  XMCA_CHECK(n_fields >= 1 && T > 0, XMCA_ERR_STATE, "bootstrap: call xmca_bootstrap_begin first");
+  const int64_t* idx_host[2] = {idx_left, idx_right};
+  FieldData<TI>* f = boot_f<TI>(h);
+  DevBuf<int64_t> idx_dev;
+  h->tm.begin("resample");
+  for (int s = 0; s < n_fields; ++s) {
+    const int64_t N = h->boot_N[s];
+    const size_t n = (size_t)T * N;
+    DevBuf<TI>& W = boot_w<TI>(h)[s];
+    if (idx_host[s]) {
+      for (int64_t t = 0; t < T; ++t) XMCA_CHECK(idx_host[s][t] >= 0 && idx_host[s][t] < T, XMCA_ERR_INVALID, "bootstrap: row index out of range");
+      XMCA_HIP(hipMemcpyAsync(idx_dev.ensure((size_t)T), idx_host[s], sizeof(int64_t) * T, hipMemcpyHostToDevice, h->st));
+      DevBuf<TI>& tmp = boot_tmp<TI>(h);
+      hipLaunchKernelGGL((gather_rows_kernel<TI>), ew_grid((int64_t)n, 4), dim3(EW_BLOCK), 0, h->st, W.get(), tmp.ensure(n), idx_dev.get(),
+                         (int)T, N);
+      XMCA_HIP(hipGetLastError());
+      XMCA_HIP(hipStreamSynchronize(h->st));      // idx_dev is reused for the other side
+      std::swap(W, tmp);                           // the resampling is cumulative (array.py:1935-1943 overwrite X_surr)
+    }
+    f[s].T = T; f[s].N = N; f[s].has_im = false; f[s].ext_re = nullptr;
+    XMCA_HIP(hipMemcpyAsync(f[s].re.ensure(n), W.get(), sizeof(TI) * n, hipMemcpyDeviceToDevice, h->st));
+    hipLaunchKernelGGL((center_columns_kernel<TI>), dim3(ceil_div(N, 256)), dim3(256), 0, h->st, f[s].re.get(), (int)T, N);   // MCA(...) ctor, array.py:117
+    XMCA_HIP(hipGetLastError());
+  }
+  h->tm.end();
+  ReplicateRunner<TI> runner(h, T, h->boot_N[0], n_fields == 2 ? h->boot_N[1] : 0, n_fields, ht_host, rotated, p, power, tol);
+  XMCA_CHECK(n_out == (rotated ? (int64_t)p : runner.rank()), XMCA_ERR_INVALID, "bootstrap: n_out must be rank (unrotated) or p (rotated)");
+  *kept = runner.run(f, spectrum, n_out);
 }
 
 }  // namespace
@@ -488,6 +579,24 @@ int xmca_project(xmca_handle* h, int side, const void* V, int64_t N, int64_t m, 
   XMCA_CHECK(V && U_out && out_is_complex && N >= 1 && m >= 1, XMCA_ERR_INVALID, "project: need an N x m matrix of vectors");
   if (h->dtype == XMCA_F32) project_impl<float>(h, side, V, N, m, is_complex != 0, U_out, out_is_complex);
   else project_impl<double>(h, side, V, N, m, is_complex != 0, U_out, out_is_complex);
+  API_END(h)
+}
+
+int xmca_bootstrap_begin(xmca_handle* h, int n_fields) {
+  API_BEGIN(h)
+  XMCA_CHECK(n_fields == 1 || n_fields == 2, XMCA_ERR_INVALID, "bootstrap: n_fields must be 1 or 2");
+  if (h->dtype == XMCA_F32) bootstrap_begin_impl<float>(h, n_fields);
+  else bootstrap_begin_impl<double>(h, n_fields);
+  API_END(h)
+}
+
+int xmca_bootstrap_run(xmca_handle* h, const double* hilbert_col, const int64_t* idx_left, const int64_t* idx_right, int rotated,
+                       int p, int power, double tol, double* spectrum_out, int* kept_out, int64_t n_out) {
+  API_BEGIN(h)
+  XMCA_CHECK(spectrum_out && kept_out && n_out >= 1, XMCA_ERR_INVALID, "bootstrap: output buffers missing");
+  XMCA_CHECK(!rotated || (p >= 2 && power >= 1), XMCA_ERR_INVALID, "bootstrap: rotation needs n_rot >= 2 and power >= 1");
+  if (h->dtype == XMCA_F32) bootstrap_run_impl<float>(h, hilbert_col, idx_left, idx_right, rotated, p, power, tol, spectrum_out, kept_out, n_out);
+  else bootstrap_run_impl<double>(h, hilbert_col, idx_left, idx_right, rotated, p, power, tol, spectrum_out, kept_out, n_out);
   API_END(h)
 }
 
