@@ -155,6 +155,9 @@ __device__ __forceinline__ void jacobi_cross_sweep_twolevel(JacTileSmem<64, fals
   for (int r = 0; r < 4; ++r) {
     // tile index of entry a (0..15) of sub-tile w
     auto tix = [r](const int w, const int a) { return a < SB ? SB * w + a : H + SB * ((w + r) & 3) + (a - SB); };
+#ifdef XMCA_JAC_PROF
+    if (tid == 0) jac_prof[((int)blockIdx.x * JAC_PROF_IT + r + 1) * JAC_PROF_ST + 2] = (long long)__builtin_readcyclecounter();
+#endif
     if (wave < 4) {
       const int w = wave, k1 = lane >> 3, k2 = lane & 7;
       double bak[4];
@@ -207,7 +210,13 @@ __device__ __forceinline__ void jacobi_cross_sweep_twolevel(JacTileSmem<64, fals
         Mr[tix(w, e >> 4)][tix(w, e & 15)] = bak[q];
       }
     }
+#ifdef XMCA_JAC_PROF
+    if (tid == 0) jac_prof[((int)blockIdx.x * JAC_PROF_IT + r + 1) * JAC_PROF_ST + 3] = (long long)__builtin_readcyclecounter();
+#endif
     __syncthreads();
+#ifdef XMCA_JAC_PROF
+    if (tid == 0) jac_prof[((int)blockIdx.x * JAC_PROF_IT + r + 1) * JAC_PROF_ST + 4] = (long long)__builtin_readcyclecounter();
+#endif
     // rows: M[idx_w, ct] <- Js_w^T M[idx_w, ct]   (set w = wave / 2, column tiles 2 (wave % 2) + {0, 1})
     {
       const int w = wave >> 1;
@@ -248,6 +257,9 @@ __device__ __forceinline__ void jacobi_cross_sweep_twolevel(JacTileSmem<64, fals
       }
     }
     __syncthreads();
+#ifdef XMCA_JAC_PROF
+    if (tid == 0) jac_prof[((int)blockIdx.x * JAC_PROF_IT + r + 1) * JAC_PROF_ST + 5] = (long long)__builtin_readcyclecounter();
+#endif
   }
 }
 
