@@ -1039,18 +1039,25 @@ __device__ __forceinline__ void jacobi_persistent_update(JacUpdSmem<NT, CPLX>& s
       if constexpr (CPLX) t.i[i] = jac_ld(ri, voff, soff);
     }
   };
+  // Operand tiles (J_P, J_Q, T) are read by the MFMA loops as S[k][16-column window] with k = k0 + lane / 16: with the
+  // plain pitch NT + 1 the two k rows of a 32-lane group start one bank pair apart and collide 2-way.  Odd rows are
+  // therefore stored rotated by 16 columns (rcol): the two windows then lie 16 / 17 bank pairs apart.  The products
+  // X, Y written back into B keep the plain layout (they are read row-wise, where the odd pitch is what is wanted).
+  auto rcol = [](const int k, const int c) { return (c + 16 * (k & 1)) & (NT - 1); };
   auto to_A = [&](const Tile& t) {
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
-      Ar[row0 + RP * i][col] = t.r[i];
-      if constexpr (CPLX) Ai[row0 + RP * i][col] = t.i[i];
+      const int rr = row0 + RP * i;
+      Ar[rr][rcol(rr, col)] = t.r[i];
+      if constexpr (CPLX) Ai[rr][rcol(rr, col)] = t.i[i];
     }
   };
   auto to_B = [&](const Tile& t) {
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
-      Br[row0 + RP * i][col] = t.r[i];
-      if constexpr (CPLX) Bi[row0 + RP * i][col] = t.i[i];
+      const int rr = row0 + RP * i;
+      Br[rr][rcol(rr, col)] = t.r[i];
+      if constexpr (CPLX) Bi[rr][rcol(rr, col)] = t.i[i];
     }
   };
   auto issue_PT = [&](const JacItem& it) {
@@ -1066,30 +1073,42 @@ __device__ __forceinline__ void jacobi_persistent_update(JacUpdSmem<NT, CPLX>& s
   // B <- A^H B   (A = J_P, B = tile), through registers
   auto mul_AhB = [&]() {
     d4_t xr[NACC], xi[CPLX ? NACC : 1];
-#pragma unroll
-    for (int a = 0; a < NACC; ++a) {
-      const int t = wave * NACC + a, ti = t / TPD, tj = t % TPD;
+    {
       // complex: three real products instead of four (the f64 matrix pipe is the bound of the update):
       //   (a - ib)(c + id):  k1 = ac, k2 = bd, k3 = (a + b)(d - c)  ->  Re = k1 + k2,  Im = k3 + k1 - k2
-      d4_t ar = {0, 0, 0, 0}, ai = {0, 0, 0, 0}, a3 = {0, 0, 0, 0};
+      d4_t k1[NACC], k2[CPLX ? NACC : 1], k3[CPLX ? NACC : 1];
+#pragma unroll
+      for (int a = 0; a < NACC; ++a) {
+        k1[a] = d4_t{0, 0, 0, 0};
+        if constexpr (CPLX) { k2[a] = d4_t{0, 0, 0, 0}; k3[a] = d4_t{0, 0, 0, 0}; }
+      }
+      const int rot = 16 * (l4 & 1);      // k = k0 + l4 and k0 is a multiple of 4
 #pragma unroll 4
       for (int k0 = 0; k0 < NT; k0 += 4) {
         const int k = k0 + l4;
-        const double jr = Ar[k][ti * 16 + l15];
-        const double tr = Br[k][tj * 16 + l15];
-        ar = Mfma<double>::mma(jr, tr, ar);
-        if constexpr (CPLX) {
-          const double ji = Ai[k][ti * 16 + l15];
-          const double tim = Bi[k][tj * 16 + l15];
-          ai = Mfma<double>::mma(ji, tim, ai);
-          a3 = Mfma<double>::mma(jr + ji, tim - tr, a3);
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) {
+          const int t = wave * NACC + a, ti = t / TPD, tj = t % TPD;
+          const int ca = (ti * 16 + l15 + rot) & (NT - 1), cb = (tj * 16 + l15 + rot) & (NT - 1);
+          const double jr = Ar[k][ca];          // (the tiles of a wave share ti: one read after CSE)
+          const double tr = Br[k][cb];
+          k1[a] = Mfma<double>::mma(jr, tr, k1[a]);
+          if constexpr (CPLX) {
+            const double ji = Ai[k][ca];
+            const double tim = Bi[k][cb];
+            k2[a] = Mfma<double>::mma(ji, tim, k2[a]);
+            k3[a] = Mfma<double>::mma(jr + ji, tim - tr, k3[a]);
+          }
         }
       }
-      if constexpr (CPLX) {
-        xr[a] = ar + ai;
-        xi[a] = a3 + ar - ai;
-      } else {
-        xr[a] = ar;
+#pragma unroll
+      for (int a = 0; a < NACC; ++a) {
+        if constexpr (CPLX) {
+          xr[a] = k1[a] + k2[a];
+          xi[a] = k3[a] + k1[a] - k2[a];
+        } else {
+          xr[a] = k1[a];
+        }
       }
     }
     __syncthreads();
@@ -1107,29 +1126,41 @@ __device__ __forceinline__ void jacobi_persistent_update(JacUpdSmem<NT, CPLX>& s
   // B <- B A   (B = X, A = J_Q)
   auto mul_BA = [&]() {
     d4_t yr[NACC], yi[CPLX ? NACC : 1];
-#pragma unroll
-    for (int a = 0; a < NACC; ++a) {
-      const int t = wave * NACC + a, ti = t / TPD, tj = t % TPD;
+    {
       //   (a + ib)(c + id):  k1 = ac, k2 = bd, k3 = (a + b)(c + d)  ->  Re = k1 - k2,  Im = k3 - k1 - k2
-      d4_t ar = {0, 0, 0, 0}, ai = {0, 0, 0, 0}, a3 = {0, 0, 0, 0};
+      d4_t k1[NACC], k2[CPLX ? NACC : 1], k3[CPLX ? NACC : 1];
+#pragma unroll
+      for (int a = 0; a < NACC; ++a) {
+        k1[a] = d4_t{0, 0, 0, 0};
+        if constexpr (CPLX) { k2[a] = d4_t{0, 0, 0, 0}; k3[a] = d4_t{0, 0, 0, 0}; }
+      }
+      const int rot = 16 * (l4 & 1);
 #pragma unroll 4
       for (int k0 = 0; k0 < NT; k0 += 4) {
         const int k = k0 + l4;
-        const double xre = Br[ti * 16 + l15][k];
-        const double qr = Ar[k][tj * 16 + l15];
-        ar = Mfma<double>::mma(xre, qr, ar);
-        if constexpr (CPLX) {
-          const double xim = Bi[ti * 16 + l15][k];
-          const double qi = Ai[k][tj * 16 + l15];
-          ai = Mfma<double>::mma(xim, qi, ai);
-          a3 = Mfma<double>::mma(xre + xim, qr + qi, a3);
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) {
+          const int t = wave * NACC + a, ti = t / TPD, tj = t % TPD;
+          const int cq = (tj * 16 + l15 + rot) & (NT - 1);
+          const double xre = Br[ti * 16 + l15][k];       // X: plain layout, read row-wise
+          const double qr = Ar[k][cq];
+          k1[a] = Mfma<double>::mma(xre, qr, k1[a]);
+          if constexpr (CPLX) {
+            const double xim = Bi[ti * 16 + l15][k];
+            const double qi = Ai[k][cq];
+            k2[a] = Mfma<double>::mma(xim, qi, k2[a]);
+            k3[a] = Mfma<double>::mma(xre + xim, qr + qi, k3[a]);
+          }
         }
       }
-      if constexpr (CPLX) {
-        yr[a] = ar - ai;
-        yi[a] = a3 - ar - ai;
-      } else {
-        yr[a] = ar;
+#pragma unroll
+      for (int a = 0; a < NACC; ++a) {
+        if constexpr (CPLX) {
+          yr[a] = k1[a] - k2[a];
+          yi[a] = k3[a] - k1[a] - k2[a];
+        } else {
+          yr[a] = k1[a];
+        }
       }
     }
     __syncthreads();
