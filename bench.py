@@ -172,6 +172,16 @@ def main():
                            "upload_only": 1e3 * upload_s, "pcs_device": 1e3 * (t4 - t3), "pcs_host_product_only": 1e3 * (t5 - t4),
                            "homogeneous_patterns": 1e3 * (t7 - t6)}
         del pcs, host_pcs, maps
+        # the same through MCA(..., preprocess='device') (centering / mean / std on the GPU)
+        t0 = time.perf_counter()
+        md = MCA(X, handle=h, preprocess='device')
+        t1 = time.perf_counter()
+        md.solve()
+        t2 = time.perf_counter()
+        md.rotate(args.n_rot, args.power)
+        t3 = time.perf_counter()
+        extra["e2e_device_preprocess_ms"] = {"ctor": 1e3 * (t1 - t0), "solve": 1e3 * (t2 - t1), "rotate": 1e3 * (t3 - t2)}
+        del md
         extra["varimax_iterations"] = m._varimax_iterations
 
     # ---- sharded rule_n (one all_gather of the spectra), bounded size ----

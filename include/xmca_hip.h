@@ -56,7 +56,8 @@ int xmca_set_field(xmca_handle* h, int side, const void* re, const void* im, int
 /* Hilbert complexify on the device: X_im = Ht * X_re for every field set so far.  Ht (T x T) is the imaginary
  * part of the analytic-signal operator, imag(scipy.signal.hilbert(eye(T), axis=0)); it is circulant, so the
  * caller passes only its first column `hilbert_col` (T float64, host): Ht[t][s] = hilbert_col[(t - s) mod T].
- * Replaces scipy.signal.hilbert(field, axis=0) of array.py:464 for extend=False. */
+ * Replaces scipy.signal.hilbert(field, axis=0) of array.py:464 for extend=False.
+ * hilbert_col == NULL reverts to the real fields (a later solve on the same resident fields is a real one again). */
 int xmca_complexify(xmca_handle* h, const double* hilbert_col);
 
 /* MCA.solve numerical core (xmca/array.py:549-584): per-field SVD, kernel, kernel SVD, back-projection.
@@ -88,6 +89,14 @@ int xmca_project(xmca_handle* h, int side, const void* V, int64_t N, int64_t m, 
  *   r_out  N x m row-major float64
  * p-values (scipy.stats.beta) stay with the caller. */
 int xmca_correlate(xmca_handle* h, int side, const double* Y, int64_t T, int64_t m, double* r_out);
+
+/* Constructor preprocessing on the device (xmca/array.py:199-215 `_set_field_means` / `_set_field_stds` / `_center`;
+ * SURVEY 8f row 3): the field of `side` set with xmca_set_field (raw, uncentered) is centered in place, column by
+ * column; mean_out / std_out (ddof = 0, float64 accumulation) get N values each and *n_nan_out the number of NaN
+ * entries found - when it is not zero nothing was changed and the caller takes its own NaN-column path. */
+int xmca_center_field(xmca_handle* h, int side, double* mean_out, double* std_out, int64_t* n_nan_out);
+/* Real plane of the resident field of `side` (T x N row-major, dtype XMCA_F32 / XMCA_F64 as it was set) -> host. */
+int xmca_get_field(xmca_handle* h, int side, void* out);
 
 /* MCA.bootstrapping (xmca/array.py:1813-1952): replicates on the device.
  * xmca_bootstrap_begin copies the real planes of the fields set with xmca_set_field (the caller's X_surr,

@@ -361,3 +361,77 @@ def test_bootstrapping_device_replicates_equal_host_loop(name, single, cplx, rot
     scale = np.abs(out[True]).max()
     tol = 2e-5 if fields[0].dtype == np.float32 else 1e-8
     assert np.max(np.abs(out[False] - out[True])) < tol * scale
+
+
+# ----------------------------------------------------------------------------------------------
+# constructor preprocessing on the device (array.py:199-215) - opt-in
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,cplx", [("wide_both", False), ("wide_both", True), ("wide_both_f32", False), ("unit_left", True)])
+def test_device_preprocessing_equals_host_constructor(name, cplx):
+    """MCA(..., preprocess='device'): means / stds / centered fields computed on the GPU and kept resident; the model
+    must be indistinguishable from the host-preprocessed one (rounding of the float64 column means aside)."""
+    fields = make_input(name)
+    ref = MCA(*fields)
+    dev = MCA(*fields, preprocess='device')
+    assert dev._store_is_raw                               # nothing was centered on the host
+    f32 = fields[0].dtype == np.float32
+    tol = 1e-5 if f32 else 1e-12
+    for k in ref._keys:
+        assert np.array_equal(dev._no_nan_index[k], ref._no_nan_index[k])
+        assert dev._field_means[k].dtype == ref._field_means[k].dtype
+        assert np.allclose(dev._field_means[k], ref._field_means[k], rtol=tol, atol=tol * np.abs(ref._field_means[k]).max())
+        assert np.allclose(dev._field_stds[k], ref._field_stds[k], rtol=tol)
+    dev.solve(complexify=cplx)
+    assert dev._store_is_raw                               # ... nor uploaded again for solve()
+    ref.solve(complexify=cplx)                             # (same default handle: takes the resident fields over)
+    k = 8
+    assert _rel(dev._singular_values[:k], ref._singular_values[:k]) < (1e-4 if f32 else 1e-10)
+    pd, pr = dev.pcs(k), ref.pcs(k)
+    for key in ref._keys:
+        ph = np.sum(np.conj(pr[key]) * pd[key], axis=0)
+        ph /= np.abs(ph)
+        assert _rel(pd[key] / ph, pr[key]) < (2e-3 if f32 else 1e-8)
+    X = dev._get_X()                                       # first host access: fetched / recomputed, analytic signal built lazily
+    assert not dev._store_is_raw
+    Xr = ref._get_X()
+    for key in ref._keys:
+        assert X[key].dtype == Xr[key].dtype and _rel(X[key], Xr[key]) < (1e-5 if f32 else 1e-12)
+    dev.solve()                                            # real again, fields now come from the host copy
+    ref.solve()
+    assert _rel(dev._singular_values[:k], ref._singular_values[:k]) < (1e-4 if f32 else 1e-10)
+
+
+def test_device_preprocessing_falls_back_for_nan_fields_and_lost_ownership():
+    sst, prcp = make_input("sst_prcp")                     # NaN columns: the reference's host path, silently
+    m = MCA(sst, prcp, preprocess='device')
+    assert not m._store_is_raw and m._fields['left'].shape == (492, 155)
+    fields = make_input("wide_both")
+    a = MCA(*fields, preprocess='device')
+    b = MCA(*make_input("small_both"))
+    b.solve()                                              # takes the handle: a's resident fields are gone
+    a.solve()
+    r = MCA(*fields)
+    r.solve()
+    assert _rel(a._singular_values[:8], r._singular_values[:8]) < 1e-10
+    with pytest.raises(ValueError):
+        MCA(*fields, preprocess='gpu')
+
+
+def test_device_preprocessing_downloads_the_centered_field_on_demand():
+    """with its own handle the model keeps the resident fields: the first host access fetches the centered field from
+    the device (and builds the analytic signal from it) instead of recomputing it."""
+    from xmca_amd import _hip
+    fields = make_input("wide_both")
+    c = MCA(*fields, handle=_hip.Handle(0), preprocess='device')
+    c.solve(complexify=True)
+    assert c._store_is_raw and c._owns_device_fields(c._device())
+    X = c._get_X()
+    assert not c._store_is_raw
+    r = MCA(*fields)
+    r.solve(complexify=True)
+    Xr = r._get_X()
+    for key in r._keys:
+        assert np.iscomplexobj(X[key]) and _rel(X[key], Xr[key]) < 1e-12
+    c.solve()                                              # and a real solve afterwards
+    r.solve()
+    assert _rel(c._singular_values[:8], r._singular_values[:8]) < 1e-10

@@ -35,6 +35,8 @@ SIGNATURES = {
     "xmca_solve": (_c_int, [_vp, _c_int, _c_i64, ctypes.POINTER(_c_i64)]),
     "xmca_get_singular_values": (_c_int, [_vp, _vp, _c_i64]),
     "xmca_get_vectors": (_c_int, [_vp, _c_int, _vp, _c_i64, _c_int]),
+    "xmca_center_field": (_c_int, [_vp, _c_int, _vp, _vp, ctypes.POINTER(_c_i64)]),
+    "xmca_get_field": (_c_int, [_vp, _c_int, _vp]),
     "xmca_bootstrap_begin": (_c_int, [_vp, _c_int]),
     "xmca_bootstrap_run": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_dbl, _vp, ctypes.POINTER(_c_int), _c_i64]),
     "xmca_correlate": (_c_int, [_vp, _c_int, _vp, _c_i64, _c_i64, _vp]),
@@ -193,6 +195,10 @@ class Handle:
         ht = hilbert_imag_column(T)
         self._check(self._lib.xmca_complexify(self._h, _ptr(ht)))
 
+    def decomplexify(self):
+        """Back to the real resident fields (undoes `complexify` for the next solve)."""
+        self._check(self._lib.xmca_complexify(self._h, None))
+
     # ---- solve --------------------------------------------------------------------------------
     def solve(self, n_fields, n_vec=-1):
         rank = _c_i64(0)
@@ -234,6 +240,21 @@ class Handle:
         if out_cplx.value:
             return out
         return out.view(np.float64).reshape(-1)[:T * m].reshape(T, m).copy()
+
+    def center_field(self, side, N):
+        """Centers the resident (raw) field of `side` in place.  Returns (mean[N], std[N], number of NaN entries); when
+        the last is not zero the field is unchanged."""
+        mean = np.empty(N, dtype=np.float64)
+        std = np.empty(N, dtype=np.float64)
+        n_nan = _c_i64(0)
+        self._check(self._lib.xmca_center_field(self._h, side, _ptr(mean), _ptr(std), ctypes.byref(n_nan)))
+        return mean, std, int(n_nan.value)
+
+    def get_field(self, side, shape, dtype):
+        """Real plane of the resident field of `side` as a (T, N) array of `dtype` (the dtype it was set with)."""
+        out = np.empty(shape, dtype=dtype)
+        self._check(self._lib.xmca_get_field(self._h, side, _ptr(out)))
+        return out
 
     def bootstrap_begin(self, n_fields):
         """Working copies of the resident fields for `bootstrap_run` (MCA.bootstrapping on the device)."""

@@ -26,7 +26,14 @@ _SCALINGS_MSG = ('The scaling option {:} is not valid. Please choose one of the 
 class MCA:
     """Maximum Covariance Analysis of one (EOF/PCA) or two `numpy.ndarray` fields; time is axis 0."""
 
-    def __init__(self, *fields, handle=None):
+    def __init__(self, *fields, handle=None, preprocess='host'):
+        """fields: one or two numpy arrays, time first.  `handle`: a `_hip.Handle` (default: one per device).
+        `preprocess='device'` (extension): the constructor's centering / mean / std pass (array.py:199-215) runs on the
+        GPU over the uploaded raw field - column means in float64 - and the centered field stays resident for solve();
+        the host copy `_fields` is fetched on first use.  Fields with NaNs, and the default `'host'`, take the
+        reference's numpy path (bit-identical means for float32 input)."""
+        if preprocess not in ('host', 'device'):
+            raise ValueError("preprocess must be 'host' or 'device'")
         if len(fields) > 2:
             raise ValueError("Too many fields. Pass 1 or 2 fields.")
         if len(fields) == 2 and fields[0].shape[0] != fields[1].shape[0]:
@@ -35,11 +42,9 @@ class MCA:
         if not all(isinstance(f, np.ndarray) for f in fields):
             raise TypeError('''One or more fields are not `numpy.ndarray`.
             Please provide `numpy.ndarray` only.''')
-        if any(has_nan_time_steps(f) for f in fields):
-            raise ValueError('''One or more fields contain NaN time steps.
-            Please remove these prior to analysis.''')
-
         self._handle_override = handle
+        self._preprocess = preprocess
+        self._store_is_raw = False
         self._keys = ['left', 'right']
         if len(fields) == 1:
             self._keys.pop()
@@ -57,7 +62,11 @@ class MCA:
         self._n_observations = {}
 
         data = {k: f for k, f in zip(self._keys, fields)}
-        self._ingest(data)
+        if not (preprocess == 'device' and self._ingest_on_device(data)):
+            if any(has_nan_time_steps(f) for f in fields):
+                raise ValueError('''One or more fields contain NaN time steps.
+            Please remove these prior to analysis.''')
+            self._ingest(data)
 
         self._analysis = {
             'version': __version__,
@@ -86,6 +95,8 @@ class MCA:
     # ------------------------------------------------------------------------------------------
     @property
     def _fields(self):
+        if self._store_is_raw:
+            self._materialize_fields()
         if self._pending_hilbert:
             from scipy.signal import hilbert
             self._fields_store = {k: hilbert(f.real, axis=0) for k, f in self._fields_store.items()}
@@ -96,6 +107,49 @@ class MCA:
     def _fields(self, value):
         self._fields_store = value
         self._pending_hilbert = False
+        self._store_is_raw = False
+
+    def _owns_device_fields(self, dev):
+        return getattr(dev, 'fields_owner', None) == (id(self), self._upload_serial)
+
+    def _ingest_on_device(self, data):
+        """preprocess='device': upload the raw fields, center them there, keep them resident.  False (nothing changed)
+        when the fields are not plain real float32/float64 arrays of one dtype or contain NaNs."""
+        if len(data) == 0:
+            return False
+        dtypes = {np.dtype(f.dtype) for f in data.values()}
+        if len(dtypes) != 1 or next(iter(dtypes)) not in (np.dtype(np.float32), np.dtype(np.float64)):
+            return False
+        dev = self._device()
+        flat = {k: np.ascontiguousarray(f.reshape(f.shape[0], int(np.prod(f.shape[1:])))) for k, f in data.items()}
+        stats = {}
+        for side, k in enumerate(self._keys):
+            dev.set_field(side, flat[k])
+            stats[k] = dev.center_field(side, flat[k].shape[1])
+            if stats[k][2]:                      # NaNs: the reference's NaN-column handling is host code
+                dev.fields_owner = None
+                return False
+        self._set_field_meta(data)
+        for k, f in flat.items():
+            self._no_nan_index[k] = np.ones(f.shape[1], dtype=bool)
+            self._field_means[k] = stats[k][0].astype(f.dtype, copy=False)
+            self._field_stds[k] = stats[k][1].astype(f.dtype, copy=False)
+        self._fields_store = flat               # raw (uncentered) views: only shape / dtype are read while `_store_is_raw`
+        self._store_is_raw = True
+        dev.fields_owner = (id(self), self._upload_serial)
+        return True
+
+    def _materialize_fields(self):
+        """Host copy of the centered fields of a device-preprocessed model: downloaded while the device still holds them,
+        otherwise recomputed from the raw input."""
+        dev = self._device()
+        if self._owns_device_fields(dev):
+            store = {k: dev.get_field(side, self._fields_store[k].shape, self._fields_store[k].dtype)
+                     for side, k in enumerate(self._keys)}
+        else:
+            store = {k: np.ascontiguousarray(remove_mean(f)) for k, f in self._fields_store.items()}
+        self._fields_store = store
+        self._store_is_raw = False
 
     def _device(self):
         return self._handle_override or _hip.default_handle()
@@ -288,7 +342,7 @@ class MCA:
         period     : season length (theta) / e-folding time (exp).
         """
         store = self._fields_store
-        if len(store) == 0 or any(np.isnan(f).all() for f in store.values()):
+        if len(store) == 0 or (not self._store_is_raw and any(np.isnan(f).all() for f in store.values())):
             raise RuntimeError('''
             Fields are empty. Did you forget to load data?
             ''')
@@ -300,6 +354,9 @@ class MCA:
         if complexify and extend:
             self._fields = self._complexify(self._fields)           # host path (nonlinear extension)
             self._device_hilbert = False
+        elif self._store_is_raw:
+            self._device_hilbert = bool(complexify)                  # centered real fields are resident already
+            self._pending_hilbert = bool(complexify)
         else:
             real = {k: self._fields[k].real if np.iscomplexobj(self._fields_store[k]) else self._fields_store[k]
                     for k in self._keys}
@@ -382,6 +439,14 @@ class MCA:
 
     def _upload_fields(self, dev):
         """Makes the fields solve() works on resident on the device and records this model as their owner."""
+        if self._store_is_raw:
+            if self._owns_device_fields(dev):                   # device-preprocessed and still resident: nothing to send
+                if self._device_hilbert:
+                    dev.complexify(self._n_observations['left'])
+                else:
+                    dev.decomplexify()
+                return
+            self._materialize_fields()                          # the handle was used elsewhere: recompute, then upload
         store = self._fields_store
         for side, k in enumerate(self._keys):
             dev.set_field(side, _device_ready(store[k]))

@@ -137,6 +137,33 @@ __global__ void center_columns_kernel(T* __restrict__ x, int rows, int64_t cols)
   for (int r = 0; r < rows; ++r) x[(int64_t)r * cols + c] = (T)((double)x[(int64_t)r * cols + c] - m);
 }
 
+// In-place column centering with statistics (the constructor's preprocessing, array.py:199-215): per column the mean,
+// the standard deviation (ddof = 0, two passes) and a NaN count; columns holding a NaN are left untouched.
+template <typename T>
+__global__ void center_columns_stats_kernel(T* __restrict__ x, int rows, int64_t cols, double* __restrict__ mean,
+                                            double* __restrict__ stdev, int* __restrict__ nan_count) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  double s = 0.0;
+  int nans = 0;
+  for (int r = 0; r < rows; ++r) {
+    const double v = (double)x[(int64_t)r * cols + c];
+    if (v != v) ++nans;
+    s += v;
+  }
+  nan_count[c] = nans;
+  const double m = s / rows;
+  mean[c] = m;
+  if (nans) { stdev[c] = m; return; }
+  double q = 0.0;
+  for (int r = 0; r < rows; ++r) {
+    const double d = (double)x[(int64_t)r * cols + c] - m;
+    q += d * d;
+    x[(int64_t)r * cols + c] = (T)d;
+  }
+  stdev[c] = sqrt(q / rows);
+}
+
 // out[t][:] = in[idx[t]][:]   (row resampling of a rows x cols matrix)
 template <typename T>
 __global__ void gather_rows_kernel(const T* __restrict__ in, T* __restrict__ out, const int64_t* __restrict__ idx, int rows,

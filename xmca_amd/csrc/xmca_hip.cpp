@@ -279,6 +279,26 @@ void correlate_impl(xmca_handle* h, int side, const double* Y, int64_t T, int64_
   XMCA_HIP(hipStreamSynchronize(h->st));
 }
 
+template <typename TI>
+void center_field_impl(xmca_handle* h, int side, double* mean_out, double* std_out, int64_t* n_nan_out) {
+  FieldData<TI>& f = fields_of<TI>(h)[side];
+  XMCA_CHECK(!f.has_im && !f.ext_re, XMCA_ERR_STATE, "center_field: needs a real field owned by the library");
+  const int64_t N = f.N;
+  DevBuf<double> mean, sd;
+  DevBuf<int> nans;
+  hipLaunchKernelGGL((center_columns_stats_kernel<TI>), dim3((unsigned)ceil_div(N, (int64_t)256)), dim3(256), 0, h->st, f.re.get(),
+                     (int)f.T, N, mean.ensure((size_t)N), sd.ensure((size_t)N), nans.ensure((size_t)N));
+  XMCA_HIP(hipGetLastError());
+  std::vector<int> nh((size_t)N);
+  XMCA_HIP(hipMemcpyAsync(mean_out, mean.get(), sizeof(double) * N, hipMemcpyDeviceToHost, h->st));
+  XMCA_HIP(hipMemcpyAsync(std_out, sd.get(), sizeof(double) * N, hipMemcpyDeviceToHost, h->st));
+  XMCA_HIP(hipMemcpyAsync(nh.data(), nans.get(), sizeof(int) * N, hipMemcpyDeviceToHost, h->st));
+  XMCA_HIP(hipStreamSynchronize(h->st));
+  int64_t total = 0;
+  for (int64_t c = 0; c < N; ++c) total += nh[(size_t)c];
+  *n_nan_out = total;
+}
+
 void fill_rot_outputs(const RotateResult& rr, bool cplx, double* R_out, double* Phi_out, double* nl, double* nr, int* iters) {
   const int p = rr.p;
   if (iters) *iters = rr.iters;
@@ -518,7 +538,13 @@ int xmca_set_field(xmca_handle* h, int side, const void* re, const void* im, int
 
 int xmca_complexify(xmca_handle* h, const double* hilbert_col) {
   API_BEGIN(h)
-  XMCA_CHECK(h->field_set[0] && hilbert_col, XMCA_ERR_STATE, "complexify: set a field first");
+  XMCA_CHECK(h->field_set[0], XMCA_ERR_STATE, "complexify: set a field first");
+  if (!hilbert_col) {            // back to the real fields (their real planes are untouched by a complex solve)
+    h->hilbert_pending = false;
+    for (int s = 0; s < 2; ++s) { h->f32[s].has_im = false; h->f64[s].has_im = false; }
+    h->solved = false;
+    return XMCA_OK;
+  }
   const int64_t T = h->dtype == XMCA_F32 ? h->f32[0].T : h->f64[0].T;
   h->hilbert_col.assign(hilbert_col, hilbert_col + T);
   h->hilbert_pending = true;      // xmca_solve decides: subspace formulation (no imaginary plane) or X_im = Ht X
@@ -579,6 +605,30 @@ int xmca_project(xmca_handle* h, int side, const void* V, int64_t N, int64_t m, 
   XMCA_CHECK(V && U_out && out_is_complex && N >= 1 && m >= 1, XMCA_ERR_INVALID, "project: need an N x m matrix of vectors");
   if (h->dtype == XMCA_F32) project_impl<float>(h, side, V, N, m, is_complex != 0, U_out, out_is_complex);
   else project_impl<double>(h, side, V, N, m, is_complex != 0, U_out, out_is_complex);
+  API_END(h)
+}
+
+int xmca_center_field(xmca_handle* h, int side, double* mean_out, double* std_out, int64_t* n_nan_out) {
+  API_BEGIN(h)
+  XMCA_CHECK(side == 0 || side == 1, XMCA_ERR_INVALID, "center_field: side must be 0 or 1");
+  XMCA_CHECK(h->field_set[side] && mean_out && std_out && n_nan_out, XMCA_ERR_STATE, "center_field: set the field first");
+  if (h->dtype == XMCA_F32) center_field_impl<float>(h, side, mean_out, std_out, n_nan_out);
+  else center_field_impl<double>(h, side, mean_out, std_out, n_nan_out);
+  API_END(h)
+}
+
+int xmca_get_field(xmca_handle* h, int side, void* out) {
+  API_BEGIN(h)
+  XMCA_CHECK((side == 0 || side == 1) && out, XMCA_ERR_INVALID, "get_field: bad arguments");
+  XMCA_CHECK(h->field_set[side], XMCA_ERR_STATE, "get_field: no field resident for this side");
+  if (h->dtype == XMCA_F32) {
+    FieldData<float>& f = h->f32[side];
+    XMCA_HIP(hipMemcpyAsync(out, f.r(), sizeof(float) * (size_t)f.T * f.N, hipMemcpyDeviceToHost, h->st));
+  } else {
+    FieldData<double>& f = h->f64[side];
+    XMCA_HIP(hipMemcpyAsync(out, f.r(), sizeof(double) * (size_t)f.T * f.N, hipMemcpyDeviceToHost, h->st));
+  }
+  XMCA_HIP(hipStreamSynchronize(h->st));
   API_END(h)
 }
 
