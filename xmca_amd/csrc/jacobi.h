@@ -1,19 +1,22 @@
 // Hermitian eigensolver for the small (T x T or N x N) stage of solve():
-// two-sided BLOCK Jacobi in f64 with round-robin pair slots.
+// two-sided BLOCK Jacobi in f64 with round-robin pair slots (NT x NT tiles: 64 real, 32 complex).
 //
-//   per round:  (1) jacobi_tile_evd_kernel   one workgroup per pair slot P diagonalises the
-//                   NT x NT diagonal tile G[P,P] with a parallel-order cyclic Jacobi held in LDS
-//                   (rotations start from the identity and always take the inner angle, so the
-//                   accumulated J_P stays close to the identity -> quadratic outer convergence);
-//               (2) jacobi_update_kernel     every off-diagonal tile  G'[P,Q] = J_P^H G[P,Q] J_Q
-//                   (upper triangle + mirrored write) and every eigenvector tile
-//                   Z'[P,c] = J_P^H Z[P,c]  on the f64 matrix pipe (v_mfma_f64_16x16x4_f64),
-//                   written straight to the slots of the NEXT round (ping-pong buffers), so the
-//                   tournament permutation costs no extra pass.
-//   after 2S-1 rounds every pair of half-blocks has met once (= one sweep).
+//   per round, ONE launch (jacobi_fused_round_kernel; problems of one or two pair slots use the plain
+//   jacobi_tile_evd_kernel + jacobi_update_kernel pair):
+//     * tile solve - the first S workgroups assemble the diagonal tiles of the NEXT round from this round's inputs
+//       (jacobi_assemble_next_diag) and sweep them once with a parallel-order cyclic Jacobi held in LDS
+//       (jacobi_tile_evd_body; two-level form jacobi_cross_sweep_twolevel for the 64 x 64 real tiles).  Rotations
+//       start from the identity and always take the inner angle, so the accumulated J_P stays close to the identity
+//       -> quadratic outer convergence;
+//     * update - all workgroups (the first S too, once done) process G'[P,Q] = J_P^H G[P,Q] J_Q (upper triangle, each
+//       quarter written once in its upper orientation) and Z'[P,c] = J_P^H Z[P,c] on the f64 matrix pipe
+//       (v_mfma_f64_16x16x4_f64) as statically assigned, software-pipelined work items (jacobi_persistent_update),
+//       written straight to the slots of the NEXT round (ping-pong buffers), so the tournament permutation costs no
+//       extra pass.
+//   after 2S-1 rounds every pair of half-blocks has met once (= one sweep); jacobi_offmax_kernel decides when to stop.
 //
 // Z accumulates Q^H: at the end row i of Z is the conjugated eigenvector i.
-// Replaces the LAPACK *gesdd calls of xmca/array.py:479 and :570 (see DESIGN.md).
+// Replaces the LAPACK *gesdd calls of xmca/array.py:479 and :570 (see DESIGN.md 2.1).
 #pragma once
 #include <algorithm>
 #include <cmath>
