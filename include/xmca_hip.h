@@ -112,7 +112,8 @@ int xmca_bootstrap_run(xmca_handle* h, const double* hilbert_col, const int64_t*
                        int p, int power, double tol, double* spectrum_out, int* kept_out, int64_t n_out);
 int xmca_is_complex(xmca_handle* h);
 /* Diagnostics of the last solve: for each of the up to three eigen-decompositions (left Gram, right Gram, kernel):
- * info[3*i + 0] = outer sweeps, info[3*i + 1] = tile size, info[3*i + 2] = pair slots.  n <= 9. */
+ * info[3*i + 0] = outer sweeps, info[3*i + 1] = tile size, info[3*i + 2] = pair slots (i = 0..2), then
+ * info[9 + i] = 1 when the eigensolver inserted a Cholesky LR step (graded spectrum).  n <= 12. */
 int xmca_get_solve_info(xmca_handle* h, int* info, int n);
 
 /* promax / varimax of xmca/tools/rotation.py:84-149, :15-78 on a host loading matrix L (N x p row-major,
@@ -152,7 +153,7 @@ int xmca_reset_timings(xmca_handle* h);
 int xmca_gemm(xmca_handle* h, const void* A, int64_t lda, int a_kfast, const void* B, int64_t ldb, int b_nfast, double* C,
               int M, int N, int K, int dtype, double alpha, int upper_only, int mirror, int splits);
 /* Hermitian eigendecomposition of an n x n host matrix (interleaved complex when is_complex):
- * lam (n, descending) and Zh (n x n, row i = conj(u_i)); info[0] = sweeps, info[1] = tile, info[2] = slots. */
+ * lam (n, descending) and Zh (n x n, row i = conj(u_i)); info (4 ints): sweeps, tile, slots, Cholesky LR step taken. */
 int xmca_eigh(xmca_handle* h, const double* A, int n, int is_complex, double* lam, double* Zh, int* info);
 /* Blocked Cholesky of an n x n Hermitian host matrix (interleaved complex when is_complex): R (n x n, upper
  * triangular, row-major, same element layout) with R^H R = A + rel_shift * max(diag A) * I; *ok = 0 when a pivot was

@@ -1,0 +1,62 @@
+"""Eigensolver probe: one matrix family per call, prints sweeps / time / residuals (environment knobs are read once per
+process, so variants are compared by running this script once per setting)."""
+import sys
+import time
+import numpy as np
+sys.path.insert(0, ".")
+from xmca_amd import _hip
+
+kind = sys.argv[1] if len(sys.argv) > 1 else "c2"
+rng = np.random.default_rng(0)
+if kind == "c2":       # Gram matrix of the bench workload (generator A, centered)
+    T, N, k = 2920, 10000, 20
+    X = (rng.standard_normal((T, k)) * np.linspace(10, 1, k)) @ rng.standard_normal((k, N)) + rng.standard_normal((T, N))
+    X -= X.mean(axis=0)
+    A = X @ X.T
+elif kind == "decay":  # geometric spectrum over 12 decades (smooth climate-like field)
+    T = 2920
+    Q, _ = np.linalg.qr(rng.standard_normal((T, T)))
+    A = (Q * np.logspace(0, -12, T)) @ Q.T
+elif kind in ("decay6", "decay3", "pow2", "pow1"):
+    T = 2920
+    Q, _ = np.linalg.qr(rng.standard_normal((T, T)))
+    lam = {"decay6": np.logspace(0, -6, T), "decay3": np.logspace(0, -3, T), "pow2": np.arange(1, T + 1) ** -2.0,
+           "pow1": np.arange(1, T + 1) ** -1.0}[kind]
+    A = (Q * lam) @ Q.T
+    A = (A + A.T) / 2
+elif kind == "cdecay":  # complex Hermitian, 8 decades
+    T = 2501
+    Q, _ = np.linalg.qr(rng.standard_normal((T, T)) + 1j * rng.standard_normal((T, T)))
+    A = (Q * np.logspace(0, -8, T)) @ Q.conj().T
+    A = (A + A.conj().T) / 2
+elif kind == "smooth":  # Gram matrix of a smooth red-noise field (AR(1) in time, squared-exponential in space)
+    T, N = 2920, 6000
+    x = np.linspace(0, 1, N)
+    k = 60
+    modes = np.cos(np.pi * np.arange(k)[:, None] * x[None, :]) * np.exp(-0.12 * np.arange(k))[:, None]
+    pcs = rng.standard_normal((T, k))
+    for t in range(1, T): pcs[t] = 0.9 * pcs[t - 1] + pcs[t] * np.sqrt(1 - 0.81)
+    X = pcs @ modes + 1e-3 * rng.standard_normal((T, N))
+    X -= X.mean(axis=0)
+    A = X @ X.T
+elif kind == "cplx":   # Hermitian, analytic-signal-like
+    T, N = 2501, 6000
+    X = rng.standard_normal((T, N)) + 1j * rng.standard_normal((T, N))
+    X[:, :30] *= 8
+    A = X @ X.conj().T
+elif kind == "small":
+    T, N = 1000, 3000
+    X = rng.standard_normal((T, N)); X -= X.mean(axis=0)
+    A = X @ X.T
+h = _hip.default_handle()
+h.eigh(A[:256, :256])
+best = 1e9
+for rep in range(3):
+    t0 = time.perf_counter(); lam, U = h.eigh(A); best = min(best, time.perf_counter() - t0)
+n = A.shape[0]
+res = np.linalg.norm(A @ U[:, :50] - U[:, :50] * lam[:50]) / np.linalg.norm(A)
+orth = np.abs(U.conj().T @ U - np.eye(n)).max()
+ref = np.linalg.eigvalsh(A)[::-1]
+resall = np.linalg.norm(A @ U - U * lam, axis=0).max() / np.abs(lam).max()
+print(kind, "sweeps", h.last_eigh_info["sweeps"], "resid_all %.2e" % resall, "ms(incl. transfers) %.1f" % (best * 1e3), "resid %.2e orth %.2e lam_err %.2e"
+      % (res, orth, np.abs(lam - ref).max() / ref[0]))

@@ -94,6 +94,52 @@ def test_eigh_rank_deficient_complex(hip):
     assert hip.last_eigh_info["sweeps"] <= 25
 
 
+@pytest.mark.parametrize("n,cplx,decades", [(700, False, 10), (500, True, 8), (1000, False, 6)])
+def test_eigh_graded_spectrum_takes_the_cholesky_lr_step(hip, n, cplx, decades):
+    """Eigenvalues spread evenly over many decades: the solver inserts one Cholesky LR step (jacobi.h) and
+    must still return orthonormal vectors - also for the small eigenvalues, which the back-transformation R^H v
+    only gives if the sweeps converge relative to sqrt(m_ii m_jj)."""
+    rng = np.random.default_rng(n)
+    Q = rng.standard_normal((n, n)) + (1j * rng.standard_normal((n, n)) if cplx else 0)
+    Q, _ = np.linalg.qr(Q)
+    lam_true = np.logspace(0, -decades, n)
+    G = (Q * lam_true) @ Q.conj().T
+    G = (G + G.conj().T) / 2
+    lam, U = hip.eigh(G)
+    assert hip.last_eigh_info["lr_step"] == 1, hip.last_eigh_info
+    ref = np.linalg.eigvalsh(G)[::-1]
+    assert np.max(np.abs(lam - ref)) < 1e-11 * ref[0]
+    assert np.max(np.abs(U.conj().T @ U - np.eye(n))) < 1e-10
+    # every eigenpair above the shift of the factorisation (1e-13 lam_max), judged at its own scale
+    big = lam_true > 1e-9
+    res = np.linalg.norm(G @ U[:, big] - U[:, big] * lam[big], axis=0)
+    assert np.max(res / ref[0]) < 1e-11
+    # the plain path agrees on the vectors of well separated (leading) eigenvalues up to phase
+    ov = np.abs(np.sum(U[:, :5].conj() * Q[:, :5], axis=0))
+    assert np.all(np.abs(ov - 1) < 1e-8)
+
+
+def test_eigh_flat_spectrum_stays_on_the_plain_path(hip):
+    rng = np.random.default_rng(5)
+    G = _herm(rng, 600, 2000, False)
+    hip.eigh(G)
+    assert hip.last_eigh_info["lr_step"] == 0
+
+
+def test_eigh_indefinite_graded_matrix(hip):
+    """Not a Gram matrix: the LR step must be skipped (or fail cleanly) and the plain sweeps finish the job."""
+    rng = np.random.default_rng(9)
+    n = 400
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    lam_true = np.logspace(0, -9, n) * np.where(np.arange(n) % 2, 1.0, -1.0)
+    G = (Q * lam_true) @ Q.T
+    G = (G + G.T) / 2
+    lam, U = hip.eigh(G)
+    ref = np.linalg.eigvalsh(G)[::-1]
+    assert np.max(np.abs(lam - ref)) < 1e-11 * np.abs(ref).max()
+    assert np.max(np.abs(U.T @ U - np.eye(n))) < 1e-10
+
+
 def test_eigh_nan_is_an_error(hip):
     G = np.eye(40)
     G[3, 5] = G[5, 3] = np.nan

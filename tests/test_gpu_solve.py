@@ -207,3 +207,42 @@ def test_small_and_ragged_shapes_match_oracle(shape_a, shape_b, cplx, dtype, tol
     assert len(s) == len(ref)
     keep = ref > 1e-8 * ref[0]
     assert np.max(np.abs(s[keep] - ref[keep]) / ref[keep]) < tol
+
+
+@pytest.mark.parametrize("two_fields,cplx", [(False, False), (True, False), (True, True)])
+def test_graded_spectrum_fields_match_oracle(two_fields, cplx):
+    """Smooth fields whose spectrum falls evenly over many decades: the eigensolver switches to its Cholesky LR
+    step (jacobi.h); singular values, loadings and the orthonormality of ALL modes must not notice."""
+    from oracle import ref_numpy as O
+    from xmca_amd.array import MCA
+    from conftest import align_modes
+    rng = np.random.default_rng(11)
+    T, N = 300, 700
+
+    def field(seed_shift):
+        k = T
+        x = np.linspace(0, 1, N)
+        modes = np.cos(np.pi * (np.arange(k)[:, None] + seed_shift) * x[None, :])
+        amp = np.logspace(0, -5, k)
+        return (rng.standard_normal((T, k)) * amp) @ modes
+
+    fields = [field(0.0)] + ([field(0.3)[:, :650]] if two_fields else [])
+    m = MCA(*fields)
+    m.solve(complexify=cplx)
+    info = m._device().solve_info()
+    assert any(e["lr_step"] for e in info), info
+    ref = O.OracleModel(*fields).solve(complexify=cplx)
+    gs = ref["singular_values"]
+    s = m._singular_values
+    # one field: sigma = lambda / dof is linear in the eigenvalues; two fields: sigma^2 = lambda(K K^H), whose absolute
+    # accuracy (~1e-13 sigma_1^2) bounds the relative accuracy of sigma by ~5e-14 (sigma_1 / sigma)^2 (DESIGN.md 2)
+    keep = gs > (3e-4 if two_fields else 1e-6) * gs[0]
+    assert np.max(np.abs(s[keep] - gs[keep]) / gs[keep]) < 1e-5
+    for side, key in enumerate(["left", "right"][:len(fields)]):
+        V = m._V[key]
+        nk = int(np.sum(keep))
+        G = V[:, :nk].conj().T @ V[:, :nk]
+        assert np.max(np.abs(G - np.eye(nk))) < (1e-5 if two_fields else 1e-9), key
+        gv = ref["V"][side][:, :6]
+        mine, _ = align_modes(V[:, :6], gv)
+        assert np.max(np.abs(mine - gv)) < 1e-5 * np.max(np.abs(gv)), key

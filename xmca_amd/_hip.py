@@ -206,9 +206,10 @@ class Handle:
         return int(rank.value)
 
     def solve_info(self):
-        info = np.zeros(9, dtype=np.int32)
-        self._check(self._lib.xmca_get_solve_info(self._h, _ptr(info), 9))
-        return [{"sweeps": int(info[3 * i]), "tile": int(info[3 * i + 1]), "slots": int(info[3 * i + 2])} for i in range(3)]
+        info = np.zeros(12, dtype=np.int32)
+        self._check(self._lib.xmca_get_solve_info(self._h, _ptr(info), 12))
+        return [{"sweeps": int(info[3 * i]), "tile": int(info[3 * i + 1]), "slots": int(info[3 * i + 2]), "lr_step": int(info[9 + i])}
+                for i in range(3)]
 
     def singular_values(self, n):
         out = np.empty(n, dtype=np.float64)
@@ -354,9 +355,9 @@ class Handle:
         n = Ad.shape[0]
         lam = np.empty(n)
         Zh = np.empty((n, n), dtype=Ad.dtype)
-        info = np.zeros(3, dtype=np.int32)
+        info = np.zeros(4, dtype=np.int32)
         self._check(self._lib.xmca_eigh(self._h, _ptr(Ad), n, int(cplx), _ptr(lam), _ptr(Zh), _ptr(info)))
-        self.last_eigh_info = {"sweeps": int(info[0]), "tile": int(info[1]), "slots": int(info[2])}
+        self.last_eigh_info = {"sweeps": int(info[0]), "tile": int(info[1]), "slots": int(info[2]), "lr_step": int(info[3])}
         return lam, Zh.conj().T
 
     def cholesky(self, A, rel_shift=0.0):

@@ -25,6 +25,7 @@
 
 #include "common.h"
 #include "gemm.h"
+#include "cholesky.h"
 
 namespace xmca {
 
@@ -40,7 +41,20 @@ __host__ __device__ inline int jacobi_dest_block(int p, int h, int S) {
   return 2 * (p - 1) + 1;
 }
 
-// scal[0] = scale of the matrix (max |diag|), scal[1] = absolute rotation floor
+// scal[3] += sum of |a_ij|^2 (the Frobenius norm bounds every eigenvalue: the padding has to sit below all of them)
+__global__ void jacobi_frobenius_kernel(const double* __restrict__ Ar, const double* __restrict__ Ai, int n, int64_t lda, double* scal) {
+  double s = 0.0;
+  for (int r = blockIdx.x; r < n; r += gridDim.x)
+    for (int c = threadIdx.x; c < n; c += blockDim.x) {
+      const double a = Ar[(int64_t)r * lda + c], b = Ai ? Ai[(int64_t)r * lda + c] : 0.0;
+      s += a * a + b * b;
+    }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) atomicAdd(scal + 3, s);
+}
+
+// scal[0] = scale of the matrix (max |diag|), scal[1] = absolute rotation floor, scal[2] = diagonal value of the padding
+// (below every eigenvalue; from scal[3] = squared Frobenius norm)
 __global__ void jacobi_init_scale_kernel(const double* __restrict__ Ar, int n, int64_t lda, double tol, double* scal) {
   __shared__ double red[256];
   double m = 0.0;
@@ -56,10 +70,11 @@ __global__ void jacobi_init_scale_kernel(const double* __restrict__ Ar, int n, i
     if (!(g > 0.0)) g = 1.0;
     scal[0] = g;
     scal[1] = 1e-13 * g;   // rotations below this absolute size are rounding noise of the null space
+    scal[2] = -2.0 * fmax(sqrt(scal[3]), g);
   }
 }
 
-// G0 = [A 0; 0 -scale*I], Z0 = I   (npad x npad, planes)
+// G0 = [A 0; 0 pad*I], Z0 = I   (npad x npad, planes; pad = scal[2])
 __global__ void jacobi_init_kernel(const double* __restrict__ Ar, const double* __restrict__ Ai, int n, int64_t lda,
                                    double* __restrict__ Gr, double* __restrict__ Gi, double* __restrict__ Zr,
                                    double* __restrict__ Zi, int npad, const double* __restrict__ scal) {
@@ -71,7 +86,7 @@ __global__ void jacobi_init_kernel(const double* __restrict__ Ar, const double* 
     gr = Ar[(int64_t)r * lda + c];
     if (Ai) gi = Ai[(int64_t)r * lda + c];
   } else if (r == c) {
-    gr = -scal[0];
+    gr = scal[2];
   }
   Gr[idx] = gr;
   if (Gi) Gi[idx] = gi;
@@ -100,24 +115,6 @@ __device__ long long jac_prof[JAC_PROF_WG * JAC_PROF_IT * JAC_PROF_ST];
 #endif
 template <int NT>
 constexpr int jac_threads() { return NT >= 64 ? XMCA_JAC_THREADS64 : 256; }
-
-// 1/sqrt(x) and 1/x for normal positive x, full double precision: hardware seed (5e-8 relative on gfx950,
-// scripts/probes/rsq_accuracy.cpp) + two Newton steps (1.4e-16; a third changes nothing)
-__device__ __forceinline__ double jac_rsqrt(const double x) {
-  double y = __builtin_amdgcn_rsq(x);
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const double h = 0.5 * x * y;
-    y = fma(y, fma(-h, y, 0.5), y);
-  }
-  return y;
-}
-__device__ __forceinline__ double jac_rcp(const double x) {
-  double y = __builtin_amdgcn_rcp(x);
-#pragma unroll
-  for (int it = 0; it < 2; ++it) y = fma(y, fma(-x, y, 1.0), y);
-  return y;
-}
 
 // LDS images of the two kernel bodies (a fused launch runs both kinds of workgroups, so they share one union)
 template <int NT, bool CPLX>
@@ -1390,26 +1387,52 @@ __global__ void jacobi_diag_kernel(const double* __restrict__ Gr, int npad, doub
   if (i < npad) d[i] = Gr[(int64_t)i * npad + i];
 }
 
-// Largest off-diagonal entry (relative to the matrix scale, entries at the rotation floor ignored) of the state a
+// Largest off-diagonal entry (relative to the matrix scale, entries at the rotation floor ignored; with `diag`, after
+// a Cholesky LR step, relative to sqrt(g_ii g_jj) - what the orthogonality of the back-transformed vectors needs) of the state a
 // sweep leaves behind.  Only the block-upper triangle of half-blocks is maintained by the fused rounds.
 __global__ void jacobi_offmax_kernel(const double* __restrict__ Gr, const double* __restrict__ Gi, int npad, int hb,
-                                     const double* __restrict__ scal, unsigned long long* __restrict__ out) {
+                                     const double* __restrict__ scal, const double* __restrict__ diag,
+                                     unsigned long long* __restrict__ out) {
   const double gscale = scal[0], floor2 = scal[1] * scal[1];
   double mx = 0.0;
   // one row per block (grid-stride over rows), columns from the row's own half-block on
   for (int r = blockIdx.x; r < npad; r += gridDim.x) {
     const int64_t row = (int64_t)r * npad;
+    const double dr = diag ? fabs(diag[r]) : 0.0;
     for (int c = (r / hb) * hb + threadIdx.x; c < npad; c += blockDim.x) {
       if (c == r) continue;
       double g2 = Gr[row + c] * Gr[row + c];
       if (Gi) g2 += Gi[row + c] * Gi[row + c];
       if (!(g2 == g2)) mx = HUGE_VAL;
+      else if (diag) { if (g2 > 0.0) mx = fmax(mx, g2 / (dr * fabs(diag[c]))); }   // scaled measure |g_ij|^2 / (g_ii g_jj)
       else if (g2 > floor2) mx = fmax(mx, g2);
     }
   }
-  if (mx < HUGE_VAL) mx = sqrt(mx) / gscale;
+  if (mx < HUGE_VAL) mx = diag ? sqrt(mx) : sqrt(mx) / gscale;
   for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
   if ((threadIdx.x & 63) == 0 && mx > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(mx));
+}
+
+// Symmetric permutation between two sweeps: G'[i][j] = G(perm[i], perm[j]), Z'[i][:] = Z[perm[i]][:].  G is read
+// through its maintained part (block-upper triangle of half-blocks, diagonal half-blocks in full).
+__global__ void jacobi_permute_kernel(const double* __restrict__ Gr, const double* __restrict__ Gi, const double* __restrict__ Zr,
+                                      const double* __restrict__ Zi, int npad, int hb, const int* __restrict__ perm,
+                                      double* __restrict__ Gor, double* __restrict__ Goi, double* __restrict__ Zor,
+                                      double* __restrict__ Zoi) {
+  const int i = blockIdx.y;
+  const int si = perm[i];
+  const int64_t orow = (int64_t)i * npad, srow = (int64_t)si * npad;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < npad; c += gridDim.x * blockDim.x) {
+    const int sj = perm[c];
+    const bool direct = si / hb <= sj / hb;
+    const int64_t src = direct ? srow + sj : (int64_t)sj * npad + si;
+    Gor[orow + c] = Gr[src];
+    if (Gi) Goi[orow + c] = direct ? Gi[src] : -Gi[src];
+    if (Zr) {
+      Zor[orow + c] = Zr[srow + c];
+      if (Zi) Zoi[orow + c] = Zi[srow + c];
+    }
+  }
 }
 
 // Zs[i][0..n) = Z[perm[i]][0..n)
@@ -1424,6 +1447,38 @@ __global__ void jacobi_gather_kernel(const double* __restrict__ Zr, const double
   }
 }
 
+// Zs[i][0..n) = Z[perm[i]][0..n) / ||Z[perm[i]][0..n)||   (one workgroup per row; after a Cholesky LR step the rows carry
+// the factor sqrt(lambda_i))
+__global__ __launch_bounds__(256) void jacobi_gather_normalize_kernel(const double* __restrict__ Zr, const double* __restrict__ Zi,
+                                                                      int npad, const int* __restrict__ perm, int n,
+                                                                      double* __restrict__ Or, double* __restrict__ Oi, int64_t ldo) {
+  __shared__ double red[4];
+  const int i = blockIdx.x;
+  const int64_t src = (int64_t)perm[i] * npad;
+  double mx = 0.0;
+  for (int c = threadIdx.x; c < n; c += 256) mx = fmax(mx, fmax(fabs(Zr[src + c]), Zi ? fabs(Zi[src + c]) : 0.0));
+  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  __syncthreads();
+  const double inv_mx = mx > 0.0 ? 1.0 / mx : 0.0;    // scaled sum of squares: rows of null modes are ~1e-7 sqrt(scale)
+  double ss = 0.0;
+  for (int c = threadIdx.x; c < n; c += 256) {
+    const double a = Zr[src + c] * inv_mx, b = Zi ? Zi[src + c] * inv_mx : 0.0;
+    ss += a * a + b * b;
+  }
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  ss = red[0] + red[1] + red[2] + red[3];
+  const double f = ss > 0.0 ? inv_mx / sqrt(ss) : 0.0;
+  for (int c = threadIdx.x; c < n; c += 256) {
+    Or[(int64_t)i * ldo + c] = Zr[src + c] * f;
+    if (Oi) Oi[(int64_t)i * ldo + c] = Zi[src + c] * f;
+  }
+}
+
 struct EvdWorkspace {
   DevBuf<double> G[2][2], Z[2][2];  // [ping-pong][plane]
   DevBuf<double> J[2][2], D[2][2];  // [round parity][plane]: rotations J_P and transformed diagonal tiles; the lookahead
@@ -1432,6 +1487,8 @@ struct EvdWorkspace {
   DevBuf<unsigned long long> off;   // one accumulator per sweep (ring)
   DevBuf<int> perm;
   DevBuf<unsigned int> work;        // one work counter per round (fused round kernel)
+  GemmWorkspace gws;                // Cholesky LR step
+  DevBuf<double> lr_R[2], lr_T[2];
 };
 
 struct EvdInfo {
@@ -1439,6 +1496,8 @@ struct EvdInfo {
   int tile = 0;
   int slots = 0;
   double last_off = 0.0;
+  int lr_step = 0;        // 1: a Cholesky LR step was inserted (graded spectrum)
+  double diag_spread = 0; // q10/q90 of the diagonal when that was decided
 };
 
 constexpr int JAC_OFF_RING = 64;
@@ -1451,6 +1510,7 @@ template <bool CPLX, int NT>
 void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, const double* Ai, int n, int64_t lda,
                         std::vector<double>& lam_host, double* lam_dev, double* Zr, double* Zi, int64_t ldz, double tol,
                         int max_sweeps, EvdInfo* info) {
+  if (info) *info = EvdInfo{};
   const int S = std::max(ceil_div(n, NT), 1);
   const int npad = S * NT;
   const size_t nn = (size_t)npad * npad;
@@ -1468,12 +1528,15 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
     }
   }
   ws.diag.ensure((size_t)npad);
-  ws.scal.ensure(2);
+  ws.scal.ensure(4);
   ws.off.ensure(JAC_OFF_RING);
   ws.perm.ensure((size_t)npad);
   if (max_sweeps > JAC_OFF_RING - 2) max_sweeps = JAC_OFF_RING - 2;   // the last slot holds the post-sweep measure
 
   XMCA_HIP(hipMemsetAsync(ws.off.get(), 0, sizeof(unsigned long long) * JAC_OFF_RING, st));
+  XMCA_HIP(hipMemsetAsync(ws.scal.get(), 0, sizeof(double) * 4, st));
+  if (npad > n)
+    hipLaunchKernelGGL(jacobi_frobenius_kernel, dim3(std::min(n, 1024)), dim3(256), 0, st, Ar, CPLX ? Ai : nullptr, n, lda, ws.scal.get());
   hipLaunchKernelGGL(jacobi_init_scale_kernel, dim3(1), dim3(256), 0, st, Ar, n, lda, tol, ws.scal.get());
   hipLaunchKernelGGL(jacobi_init_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, Ar, CPLX ? Ai : nullptr, n, lda,
                      ws.G[0][0].get(), CPLX ? ws.G[0][1].get() : nullptr, want_z ? ws.Z[0][0].get() : nullptr,
@@ -1542,6 +1605,8 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
   int sweeps = 0;
   double off = 0.0;
   int64_t round_no = 0;
+  bool lr_applied = false;
+  double lr_delta = 0.0;
   if (lookahead) evd(st, cur, 0, 0, 0);  // diagonal tiles of the very first round
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
     for (int r = 0; r < rounds; ++r, ++round_no) {
@@ -1587,8 +1652,10 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
     unsigned long long bits[2] = {0, 0};
     if (S > 1) {
       XMCA_HIP(hipMemsetAsync(ws.off.get() + JAC_OFF_RING - 1, 0, sizeof(unsigned long long), st));
+      if (lr_applied)
+        hipLaunchKernelGGL(jacobi_diag_kernel, dim3(ceil_div(npad, 256)), dim3(256), 0, st, ws.G[cur][0].get(), npad, ws.diag.get());
       hipLaunchKernelGGL(jacobi_offmax_kernel, dim3(2048), dim3(256), 0, st, ws.G[cur][0].get(), CPLX ? ws.G[cur][1].get() : nullptr,
-                         npad, NT / 2, ws.scal.get(), ws.off.get() + JAC_OFF_RING - 1);
+                         npad, NT / 2, ws.scal.get(), lr_applied ? ws.diag.get() : nullptr, ws.off.get() + JAC_OFF_RING - 1);
       XMCA_HIP(hipMemcpyAsync(&bits[1], ws.off.get() + JAC_OFF_RING - 1, sizeof(bits[1]), hipMemcpyDeviceToHost, st));
     }
     XMCA_HIP(hipMemcpyAsync(&bits[0], ws.off.get() + sweep, sizeof(bits[0]), hipMemcpyDeviceToHost, st));
@@ -1601,6 +1668,72 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
     if (trace) std::fprintf(stderr, "[xmca jacobi] n=%d NT=%d cplx=%d sweep %d: max off/scale seen = %.3e, left = %.3e\n", n, NT, (int)CPLX, sweeps, off, left);
     if (S == 1) break;
     if (!(left >= tol) || !std::isfinite(left)) { off = left; break; }
+    // Cholesky LR step for graded spectra.  With eigenvalues spread evenly over many decades the couplings between
+    // large and small eigenvalues have to fall far below the small ones before those start to converge, and the
+    // sweeps only converge linearly (measured: 30 sweeps for 12 decades at n = 2920, 12 for a flat bulk).  One step of
+    // the Cholesky LR iteration, G + delta I = R^H R -> M = R R^H (= R G R^-1 + delta I), removes exactly these
+    // long-range couplings (11 sweeps for the same matrix); it costs about one sweep, so it is taken only when the
+    // diagonal after `lr_after` sweeps says the spectrum is graded.  Z <- R Z turns the accumulated rows into
+    // sqrt(lambda_i) x eigenvector, which the final gather normalises.
+    static const int lr_mode = [] { const char* e = std::getenv("XMCA_JACOBI_LR"); return e ? std::atoi(e) : 1; }();   // 0 off, 1 auto, 2 always
+    static const double lr_spread = [] { const char* e = std::getenv("XMCA_JACOBI_LR_SPREAD"); return e ? std::atof(e) : 100.0; }();
+    static const int lr_after = [] { const char* e = std::getenv("XMCA_JACOBI_LR_AFTER"); return e ? std::max(std::atoi(e), 1) : 2; }();
+    if (lookahead && lr_mode != 0 && sweeps == lr_after && !lr_applied) {
+      hipLaunchKernelGGL(jacobi_diag_kernel, dim3(ceil_div(npad, 256)), dim3(256), 0, st, ws.G[cur][0].get(), npad, ws.diag.get());
+      std::vector<double> dd(npad);
+      XMCA_HIP(hipMemcpyAsync(dd.data(), ws.diag.get(), sizeof(double) * npad, hipMemcpyDeviceToHost, st));
+      XMCA_HIP(hipStreamSynchronize(st));
+      std::vector<int> pm(npad);
+      for (int i = 0; i < npad; ++i) pm[i] = i;
+      std::stable_sort(pm.begin(), pm.end(), [&](int a, int b) { return dd[a] > dd[b]; });
+      // the padding (-scale, decoupled) must be what sorts last; a matrix with diagonal entries down there is not a
+      // Gram matrix and stays on the plain path
+      const double dmax = dd[pm[0]], dmin = dd[pm[n - 1]];
+      const double q10 = dd[pm[n / 10]], q90 = std::max(dd[pm[(int64_t)n * 9 / 10]], 1e-14 * dmax);
+      const double spread = (dmax > 0.0 && q10 > 0.0) ? q10 / q90 : 0.0;
+      if (info) info->diag_spread = spread;
+      if (dmin > -0.25 * dmax && dmax > 0.0 && std::isfinite(dmax) && (lr_mode == 2 || spread > lr_spread)) {
+        XMCA_HIP(hipMemcpyAsync(ws.perm.get(), pm.data(), sizeof(int) * npad, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(jacobi_permute_kernel, dim3(std::min(ceil_div(npad, 256), 16), npad), dim3(256), 0, st, ws.G[cur][0].get(),
+                           CPLX ? ws.G[cur][1].get() : nullptr, want_z ? ws.Z[cur][0].get() : nullptr,
+                           (CPLX && want_z) ? ws.Z[cur][1].get() : nullptr, npad, NT / 2, ws.perm.get(), ws.G[cur ^ 1][0].get(),
+                           CPLX ? ws.G[cur ^ 1][1].get() : nullptr, want_z ? ws.Z[cur ^ 1][0].get() : nullptr,
+                           (CPLX && want_z) ? ws.Z[cur ^ 1][1].get() : nullptr);
+        XMCA_HIP(hipGetLastError());
+        cur ^= 1;
+        const size_t row = sizeof(double) * (size_t)n, pitch = sizeof(double) * (size_t)npad;
+        for (int pl = 0; pl < (CPLX ? 2 : 1); ++pl) {
+          ws.lr_R[pl].ensure((size_t)n * n);
+          XMCA_HIP(hipMemcpy2DAsync(ws.lr_R[pl].get(), row, ws.G[cur][pl].get(), pitch, row, n, hipMemcpyDeviceToDevice, st));
+        }
+        double* Rr = ws.lr_R[0].get();
+        double* Ri = CPLX ? ws.lr_R[1].get() : nullptr;
+        const double rel_shift = 1e-13;
+        if (cholesky_upper(st, ws.gws, Rr, Ri, n, n, rel_shift)) {
+          // M = R R^H over the leading block of G (the padding stays decoupled)
+          cgemm<double>(st, ws.gws, Rr, Ri, n, true, false, Rr, Ri, n, false, true, ws.G[cur][0].get(),
+                        CPLX ? ws.G[cur][1].get() : nullptr, npad, n, n, n, 1.0, nullptr, nullptr, true);
+          if (want_z) {
+            for (int pl = 0; pl < (CPLX ? 2 : 1); ++pl) ws.lr_T[pl].ensure((size_t)n * n);
+            cgemm<double>(st, ws.gws, Rr, Ri, n, true, false, ws.Z[cur][0].get(), CPLX ? ws.Z[cur][1].get() : nullptr, npad, true, false,
+                          ws.lr_T[0].get(), CPLX ? ws.lr_T[1].get() : nullptr, n, n, n, n, 1.0, nullptr, nullptr, false);
+            for (int pl = 0; pl < (CPLX ? 2 : 1); ++pl)
+              XMCA_HIP(hipMemcpy2DAsync(ws.Z[cur][pl].get(), pitch, ws.lr_T[pl].get(), row, row, n, hipMemcpyDeviceToDevice, st));
+          }
+          lr_applied = true;
+          lr_delta = rel_shift * dmax;
+          // M is positive definite with a meaningful (graded) diagonal: from here on rotations and the stopping rule are
+          // relative to sqrt(m_ii m_jj) alone - the orthogonality of the back-transformed vectors is the scaled
+          // off-diagonal part of the final M - and the absolute rotation floor is dropped
+          XMCA_HIP(hipMemsetAsync(ws.scal.get() + 1, 0, sizeof(double), st));
+        }
+        XMCA_HIP(hipStreamSynchronize(st));   // pm goes out of scope
+        evd(st, cur, (int)(round_no & 1), sweep + 1, 0);   // the lookahead solve of the next round saw the old matrix
+        if (trace) std::fprintf(stderr, "[xmca jacobi] n=%d diagonal spread q10/q90 = %.3e: Cholesky LR step %s\n", n, spread, lr_applied ? "taken" : "failed (not positive definite)");
+      } else if (trace) {
+        std::fprintf(stderr, "[xmca jacobi] n=%d diagonal spread q10/q90 = %.3e: no LR step\n", n, spread);
+      }
+    }
   }
   XMCA_CHECK(std::isfinite(off), XMCA_ERR_NUMERIC, "SVD failed. NaN entries may be the problem.");
 
@@ -1613,16 +1746,20 @@ void hermitian_evd_impl(hipStream_t st, EvdWorkspace& ws, const double* Ar, cons
   for (int i = 0; i < npad; ++i) perm[i] = i;
   std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return d[a] > d[b]; });
   lam_host.resize(n);
-  for (int i = 0; i < n; ++i) lam_host[i] = d[perm[i]];
+  for (int i = 0; i < n; ++i) lam_host[i] = d[perm[i]] - lr_delta;
   XMCA_HIP(hipMemcpyAsync(ws.perm.get(), perm.data(), sizeof(int) * n, hipMemcpyHostToDevice, st));
   if (lam_dev) XMCA_HIP(hipMemcpyAsync(lam_dev, lam_host.data(), sizeof(double) * n, hipMemcpyHostToDevice, st));
-  if (Zr) {
+  if (Zr && lr_applied) {
+    hipLaunchKernelGGL(jacobi_gather_normalize_kernel, dim3(n), dim3(256), 0, st, ws.Z[cur][0].get(), CPLX ? ws.Z[cur][1].get() : nullptr,
+                       npad, ws.perm.get(), n, Zr, CPLX ? Zi : nullptr, ldz);
+    XMCA_HIP(hipGetLastError());
+  } else if (Zr) {
     hipLaunchKernelGGL(jacobi_gather_kernel, dim3(std::min(ceil_div(n, 256), 64), n), dim3(256), 0, st, ws.Z[cur][0].get(),
                        CPLX ? ws.Z[cur][1].get() : nullptr, npad, ws.perm.get(), n, Zr, CPLX ? Zi : nullptr, ldz);
     XMCA_HIP(hipGetLastError());
   }
   XMCA_HIP(hipStreamSynchronize(st));   // perm / lam_host staging buffers go out of scope
-  if (info) { info->sweeps = sweeps; info->tile = NT; info->slots = S; info->last_off = off; }
+  if (info) { info->sweeps = sweeps; info->tile = NT; info->slots = S; info->last_off = off; info->lr_step = lr_applied ? 1 : 0; }
 }
 
 inline void hermitian_evd(hipStream_t st, EvdWorkspace& ws, const double* Ar, const double* Ai, int n, int64_t lda,

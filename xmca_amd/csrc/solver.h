@@ -78,99 +78,6 @@ struct FieldData {
   const TI* i() const { return has_im ? (ext_im ? ext_im : im.get()) : nullptr; }
 };
 
-// C = alpha * rs * cs * opA(A) * opB(B) on complex planes through 1-4 real MFMA GEMMs.
-//   conj flags negate the imaginary plane of the operand; `herm` computes only the upper block triangle and
-//   mirrors (C must then be Hermitian by construction).
-template <typename TI>
-void cgemm(hipStream_t st, GemmWorkspace& ws, const TI* Ar, const TI* Ai, int64_t lda, bool a_kfast, bool conjA, const TI* Br,
-           const TI* Bi, int64_t ldb, bool b_nfast, bool conjB, double* Cr, double* Ci, int64_t ldc, int M, int N, int K,
-           double alpha, const double* row_scale, const double* col_scale, bool herm, double beta0 = 0.0) {
-  // beta0: C = ... + beta0 * C (both planes)
-  GemmOpts o;
-  o.a_kfast = a_kfast;
-  o.b_nfast = b_nfast;
-  o.row_scale = row_scale;
-  o.col_scale = col_scale;
-  o.upper_only = herm;
-  const double sa = conjA ? -1.0 : 1.0, sb = conjB ? -1.0 : 1.0;
-  // real part: Ar Br - sa sb Ai Bi
-  o.alpha = alpha; o.beta = beta0; o.mirror = herm ? 1 : 0;
-  gemm<TI, double>(st, ws, Ar, lda, Br, ldb, Cr, ldc, M, N, K, o);
-  if (Ai && Bi) {
-    o.alpha = -sa * sb * alpha; o.beta = 1.0;
-    gemm<TI, double>(st, ws, Ai, lda, Bi, ldb, Cr, ldc, M, N, K, o);
-  }
-  if (!Ci) return;
-  // imaginary part: sb Ar Bi + sa Ai Br
-  o.mirror = herm ? -1 : 0;
-  bool first = true;
-  if (Bi) {
-    o.alpha = sb * alpha; o.beta = beta0;
-    gemm<TI, double>(st, ws, Ar, lda, Bi, ldb, Ci, ldc, M, N, K, o);
-    first = false;
-  }
-  if (Ai) {
-    o.alpha = sa * alpha; o.beta = first ? beta0 : 1.0;
-    gemm<TI, double>(st, ws, Ai, lda, Br, ldb, Ci, ldc, M, N, K, o);
-    first = false;
-  }
-  if (first && beta0 == 0.0) XMCA_HIP(hipMemsetAsync(Ci, 0, sizeof(double) * (size_t)M * ldc, st));
-}
-
-// Blocked Cholesky G + delta I = R^H R (R upper triangular) in place on the planes of an n x n Hermitian matrix whose
-// upper triangle is valid; delta = rel_shift * max diag (semi-definite Gram matrices of centered / analytic fields).
-// On return the strictly lower triangle is zero, so R is a dense GEMM operand.  Returns false when a pivot was not
-// positive (the caller then takes the eigen-decomposition route).  Panels of CHOL_NB columns: diagonal block and its
-// inverse in one workgroup, row panel R12 = R11^{-H} A12 and trailing update A22 -= R12^H R12 as MFMA GEMMs.
-inline bool cholesky_upper(hipStream_t st, GemmWorkspace& ws, double* Gr, double* Gi, int n, int64_t ld, double rel_shift) {
-  const bool cplx = Gi != nullptr;
-  DevBuf<double> rinv_r, rinv_i, tmp_r, tmp_i;
-  DevBuf<unsigned long long> mx;
-  DevBuf<int> fail;
-  rinv_r.ensure((size_t)CHOL_NB * CHOL_NB);
-  if (cplx) rinv_i.ensure((size_t)CHOL_NB * CHOL_NB);
-  tmp_r.ensure((size_t)CHOL_NB * n);
-  if (cplx) tmp_i.ensure((size_t)CHOL_NB * n);
-  XMCA_HIP(hipMemsetAsync(mx.ensure(1), 0, sizeof(unsigned long long), st));
-  XMCA_HIP(hipMemsetAsync(fail.ensure(1), 0, sizeof(int), st));
-  hipLaunchKernelGGL(chol_max_diag_kernel, dim3(std::min(ceil_div(n, 256), 64)), dim3(256), 0, st, Gr, ld, n, mx.get());
-  unsigned long long bits = 0;
-  XMCA_HIP(hipMemcpyAsync(&bits, mx.get(), sizeof(bits), hipMemcpyDeviceToHost, st));
-  XMCA_HIP(hipStreamSynchronize(st));
-  double maxdiag = 0.0;
-  std::memcpy(&maxdiag, &bits, sizeof(double));
-  if (!(maxdiag > 0.0) || !std::isfinite(maxdiag)) return false;
-  hipLaunchKernelGGL(chol_shift_diag_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, Gr, ld, n, rel_shift * maxdiag);
-  for (int k0 = 0; k0 < n; k0 += CHOL_NB) {
-    const int nb = std::min(CHOL_NB, n - k0), rest = n - k0 - nb;
-    if (cplx)
-      hipLaunchKernelGGL((chol_diag_kernel<true>), dim3(1), dim3(256), 0, st, Gr, Gi, ld, k0, nb, rinv_r.get(), rinv_i.get(), fail.get());
-    else
-      hipLaunchKernelGGL((chol_diag_kernel<false>), dim3(1), dim3(256), 0, st, Gr, (double*)nullptr, ld, k0, nb, rinv_r.get(),
-                         (double*)nullptr, fail.get());
-    XMCA_HIP(hipGetLastError());
-    if (rest <= 0) break;
-    const int64_t o12 = (int64_t)k0 * ld + k0 + nb, o22 = (int64_t)(k0 + nb) * ld + k0 + nb;
-    // R12 = Rinv^H A12   (nb x rest)
-    cgemm<double>(st, ws, rinv_r.get(), cplx ? rinv_i.get() : nullptr, CHOL_NB, false, true, Gr + o12, cplx ? Gi + o12 : nullptr, ld,
-                  true, false, tmp_r.get(), cplx ? tmp_i.get() : nullptr, rest, nb, rest, nb, 1.0, nullptr, nullptr, false);
-    hipLaunchKernelGGL(chol_place_kernel, ew_grid((int64_t)nb * rest), dim3(EW_BLOCK), 0, st, tmp_r.get(), (int64_t)rest, Gr, ld, k0,
-                       k0 + nb, nb, rest);
-    if (cplx)
-      hipLaunchKernelGGL(chol_place_kernel, ew_grid((int64_t)nb * rest), dim3(EW_BLOCK), 0, st, tmp_i.get(), (int64_t)rest, Gi, ld, k0,
-                         k0 + nb, nb, rest);
-    // A22 -= R12^H R12   (upper block triangle, mirrored)
-    cgemm<double>(st, ws, tmp_r.get(), cplx ? tmp_i.get() : nullptr, rest, false, true, tmp_r.get(), cplx ? tmp_i.get() : nullptr, rest,
-                  true, false, Gr + o22, cplx ? Gi + o22 : nullptr, ld, rest, rest, nb, -1.0, nullptr, nullptr, true, 1.0);
-  }
-  hipLaunchKernelGGL(chol_zero_lower_kernel, ew_grid((int64_t)n * n), dim3(EW_BLOCK), 0, st, Gr, Gi, ld, n);
-  XMCA_HIP(hipGetLastError());
-  int failed = 0;
-  XMCA_HIP(hipMemcpyAsync(&failed, fail.get(), sizeof(int), hipMemcpyDeviceToHost, st));
-  XMCA_HIP(hipStreamSynchronize(st));
-  return failed == 0;
-}
-
 template <typename TO>
 static void launch_convert(hipStream_t st, const double* in, TO* out, int64_t n) {
   if (n <= 0) return;

@@ -581,6 +581,7 @@ int xmca_get_solve_info(xmca_handle* h, int* info, int n) {
     const EvdInfo& e = h->res.evd_info[i / 3];
     info[i] = (i % 3 == 0) ? e.sweeps : (i % 3 == 1) ? e.tile : e.slots;
   }
+  for (int i = 9; i < n && i < 12; ++i) info[i] = h->res.evd_info[i - 9].lr_step;
   return XMCA_OK;
 }
 
@@ -822,7 +823,7 @@ int xmca_eigh(xmca_handle* h, const double* A, int n, int is_complex, double* la
   EvdInfo ei;
   hermitian_evd(h->st, h->ews, Ap.r(), Ap.i(cplx), n, n, lh, nullptr, Zp.r(), Zp.i(cplx), n, &ei);
   std::memcpy(lam, lh.data(), sizeof(double) * n);
-  if (info) { info[0] = ei.sweeps; info[1] = ei.tile; info[2] = ei.slots; }
+  if (info) { info[0] = ei.sweeps; info[1] = ei.tile; info[2] = ei.slots; info[3] = ei.lr_step; }
   if (Zh) {
     const size_t no = nn * (cplx ? 2 : 1);
     hipLaunchKernelGGL((pack_rows_kernel<double>), ew_grid((int64_t)nn), dim3(EW_BLOCK), 0, h->st, Zp.r(), Zp.i(cplx), (int64_t)n, n, n,
