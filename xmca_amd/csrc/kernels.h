@@ -23,6 +23,10 @@ __device__ __forceinline__ double jac_rcp(const double x) {
   return y;
 }
 
+// single precision: the hardware seeds are accurate to 1 ulp
+__device__ __forceinline__ float jac_rsqrt(const float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float jac_rcp(const float x) { return __builtin_amdgcn_rcpf(x); }
+
 constexpr int EW_BLOCK = 256;
 static inline dim3 ew_grid(int64_t n, int per_thread = 1) {
   int64_t b = (n + (int64_t)EW_BLOCK * per_thread - 1) / ((int64_t)EW_BLOCK * per_thread);
