@@ -95,6 +95,11 @@ int xmca_correlate(xmca_handle* h, int side, const double* Y, int64_t T, int64_t
  * column; mean_out / std_out (ddof = 0, float64 accumulation) get N values each and *n_nan_out the number of NaN
  * entries found - when it is not zero nothing was changed and the caller takes its own NaN-column path. */
 int xmca_center_field(xmca_handle* h, int side, double* mean_out, double* std_out, int64_t* n_nan_out);
+/* NaN-column handling of the constructor on the device (xmca/array.py:191-197 `_set_no_nan_idx`, `_remove_nan_cols`,
+ * tools/array.py:27-62): keep_out[c] = 1 for every column of the resident raw field of `side` that holds no NaN
+ * (N ints), *n_keep_out their number; the resident field is replaced by those columns (T x n_keep, order kept).
+ * With n_keep = 0 the field is left as it is (the caller raises the reference's error). */
+int xmca_compact_field(xmca_handle* h, int side, int* keep_out, int64_t* n_keep_out);
 /* Real plane of the resident field of `side` (T x N row-major, dtype XMCA_F32 / XMCA_F64 as it was set) -> host. */
 int xmca_get_field(xmca_handle* h, int side, void* out);
 

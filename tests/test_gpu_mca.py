@@ -401,10 +401,39 @@ def test_device_preprocessing_equals_host_constructor(name, cplx):
     assert _rel(dev._singular_values[:k], ref._singular_values[:k]) < (1e-4 if f32 else 1e-10)
 
 
-def test_device_preprocessing_falls_back_for_nan_fields_and_lost_ownership():
-    sst, prcp = make_input("sst_prcp")                     # NaN columns: the reference's host path, silently
-    m = MCA(sst, prcp, preprocess='device')
-    assert not m._store_is_raw and m._fields['left'].shape == (492, 155)
+@pytest.mark.parametrize("own_handle", [False, True])
+def test_device_preprocessing_drops_nan_columns_on_the_device(own_handle):
+    """fields with NaN columns (land / sea masks): mask, compaction, means and centering all on the device
+    (xmca_compact_field + xmca_center_field) - same model as the host constructor (array.py:191-215)."""
+    from xmca_amd import _hip
+    sst, prcp = make_input("sst_prcp")                     # NaN columns in both fields
+    ref = MCA(sst, prcp)
+    dev = MCA(sst, prcp, preprocess='device', **({"handle": _hip.Handle(0)} if own_handle else {}))
+    assert dev._store_is_raw
+    f32 = sst.dtype == np.float32
+    for k in ref._keys:
+        assert np.array_equal(dev._no_nan_index[k], ref._no_nan_index[k])
+        assert np.allclose(dev._field_means[k], ref._field_means[k], rtol=1e-5 if f32 else 1e-12, atol=1e-5 if f32 else 1e-12)
+        assert np.allclose(dev._field_stds[k], ref._field_stds[k], rtol=1e-5 if f32 else 1e-12)
+    dev.solve()
+    ref.solve()                                            # (default handle: takes the resident fields over unless dev has its own)
+    assert _rel(dev._singular_values[:8], ref._singular_values[:8]) < (1e-4 if f32 else 1e-10)
+    assert dev._V['left'].shape == ref._V['left'].shape and dev._V['right'].shape == ref._V['right'].shape
+    X, Xr = dev._get_X(), ref._get_X()                     # downloaded (own handle) or recomputed from the raw input
+    for key in ref._keys:
+        assert X[key].shape == Xr[key].shape == (492, int(ref._no_nan_index[key].sum()))
+        assert _rel(X[key], Xr[key]) < (1e-5 if f32 else 1e-12)
+    pd, pr = dev.eofs(3), ref.eofs(3)                      # NaN columns come back as NaN in the spatial patterns
+    for key in ref._keys:
+        assert pd[key].shape == pr[key].shape and np.array_equal(np.isnan(pd[key]), np.isnan(pr[key]))
+
+
+def test_device_preprocessing_falls_back_and_lost_ownership():
+    bad = np.random.default_rng(0).standard_normal((30, 12))
+    bad[:, :] = np.where(np.arange(12) % 2 == 0, np.nan, bad)     # half the columns NaN: fine
+    bad[5, :] = np.nan                                              # ... and one NaN time step: every column has a NaN
+    with pytest.raises(ValueError):
+        MCA(bad, preprocess='device')                               # the host path raises the reference's error
     fields = make_input("wide_both")
     a = MCA(*fields, preprocess='device')
     b = MCA(*make_input("small_both"))

@@ -36,6 +36,7 @@ SIGNATURES = {
     "xmca_get_singular_values": (_c_int, [_vp, _vp, _c_i64]),
     "xmca_get_vectors": (_c_int, [_vp, _c_int, _vp, _c_i64, _c_int]),
     "xmca_center_field": (_c_int, [_vp, _c_int, _vp, _vp, ctypes.POINTER(_c_i64)]),
+    "xmca_compact_field": (_c_int, [_vp, _c_int, _vp, ctypes.POINTER(_c_i64)]),
     "xmca_get_field": (_c_int, [_vp, _c_int, _vp]),
     "xmca_bootstrap_begin": (_c_int, [_vp, _c_int]),
     "xmca_bootstrap_run": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_dbl, _vp, ctypes.POINTER(_c_int), _c_i64]),
@@ -250,6 +251,13 @@ class Handle:
         n_nan = _c_i64(0)
         self._check(self._lib.xmca_center_field(self._h, side, _ptr(mean), _ptr(std), ctypes.byref(n_nan)))
         return mean, std, int(n_nan.value)
+
+    def compact_field(self, side, N):
+        """Drops the NaN columns of the resident raw field of `side`.  Returns (keep mask[N], number of kept columns)."""
+        keep = np.empty(N, dtype=np.int32)
+        n_keep = _c_i64(0)
+        self._check(self._lib.xmca_compact_field(self._h, side, _ptr(keep), ctypes.byref(n_keep)))
+        return keep.astype(bool), int(n_keep.value)
 
     def get_field(self, side, shape, dtype):
         """Real plane of the resident field of `side` as a (T, N) array of `dtype` (the dtype it was set with)."""

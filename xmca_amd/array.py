@@ -23,6 +23,24 @@ from .tools.text import boldify_str, secure_str, wrap_str
 _SCALINGS_MSG = ('The scaling option {:} is not valid. Please choose one of the following: None, eigen, std, max')
 
 
+class _RawField:
+    """Stand-in for a field that was preprocessed on the device (MCA(..., preprocess='device')): the raw input, the
+    mask of its NaN-free columns, and the shape / dtype the centered field has."""
+
+    def __init__(self, raw, keep):
+        self.raw = raw
+        self.keep = keep
+        self.shape = (raw.shape[0], int(np.count_nonzero(keep)))
+        self.dtype = raw.dtype
+
+    @property
+    def real(self):
+        return self
+
+    def kept_columns(self):
+        return self.raw if self.shape[1] == self.raw.shape[1] else self.raw[:, self.keep]
+
+
 class MCA:
     """Maximum Covariance Analysis of one (EOF/PCA) or two `numpy.ndarray` fields; time is axis 0."""
 
@@ -113,8 +131,9 @@ class MCA:
         return getattr(dev, 'fields_owner', None) == (id(self), self._upload_serial)
 
     def _ingest_on_device(self, data):
-        """preprocess='device': upload the raw fields, center them there, keep them resident.  False (nothing changed)
-        when the fields are not plain real float32/float64 arrays of one dtype or contain NaNs."""
+        """preprocess='device': upload the raw fields, drop their NaN columns and center them there, keep them resident.
+        False (nothing changed) when the fields are not plain real float32/float64 arrays of one dtype, or when a
+        field has no NaN-free column (the host path then raises the reference's errors)."""
         if len(data) == 0:
             return False
         dtypes = {np.dtype(f.dtype) for f in data.values()}
@@ -122,19 +141,22 @@ class MCA:
             return False
         dev = self._device()
         flat = {k: np.ascontiguousarray(f.reshape(f.shape[0], int(np.prod(f.shape[1:])))) for k, f in data.items()}
-        stats = {}
+        stats, keep = {}, {}
         for side, k in enumerate(self._keys):
             dev.set_field(side, flat[k])
-            stats[k] = dev.center_field(side, flat[k].shape[1])
-            if stats[k][2]:                      # NaNs: the reference's NaN-column handling is host code
+            keep[k], n_keep = dev.compact_field(side, flat[k].shape[1])      # array.py:191-197 on the device
+            if n_keep == 0:
                 dev.fields_owner = None
                 return False
+            stats[k] = dev.center_field(side, n_keep)
         self._set_field_meta(data)
+        store = {}
         for k, f in flat.items():
-            self._no_nan_index[k] = np.ones(f.shape[1], dtype=bool)
+            self._no_nan_index[k] = keep[k]
             self._field_means[k] = stats[k][0].astype(f.dtype, copy=False)
             self._field_stds[k] = stats[k][1].astype(f.dtype, copy=False)
-        self._fields_store = flat               # raw (uncentered) views: only shape / dtype are read while `_store_is_raw`
+            store[k] = _RawField(f, keep[k])
+        self._fields_store = store              # stand-ins: only shape / dtype are read while `_store_is_raw`
         self._store_is_raw = True
         dev.fields_owner = (id(self), self._upload_serial)
         return True
@@ -147,7 +169,7 @@ class MCA:
             store = {k: dev.get_field(side, self._fields_store[k].shape, self._fields_store[k].dtype)
                      for side, k in enumerate(self._keys)}
         else:
-            store = {k: np.ascontiguousarray(remove_mean(f)) for k, f in self._fields_store.items()}
+            store = {k: np.ascontiguousarray(remove_mean(f.kept_columns())) for k, f in self._fields_store.items()}
         self._fields_store = store
         self._store_is_raw = False
 

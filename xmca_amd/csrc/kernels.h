@@ -186,6 +186,30 @@ __global__ void center_columns_stats_kernel(T* __restrict__ x, int rows, int64_t
   stdev[c] = sqrt(q / rows);
 }
 
+// nan_count[c] = number of NaN entries of column c (one thread per column, coalesced over columns)
+template <typename T>
+__global__ void column_nan_count_kernel(const T* __restrict__ x, int rows, int64_t cols, int* __restrict__ nan_count) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  int nans = 0;
+  for (int r = 0; r < rows; ++r) {
+    const T v = x[(int64_t)r * cols + c];
+    if (v != v) ++nans;
+  }
+  nan_count[c] = nans;
+}
+
+// out[r][j] = in[r][idx[j]]   (column selection: rows x cols_in -> rows x cols_out)
+template <typename T>
+__global__ void gather_columns_kernel(const T* __restrict__ in, int64_t cols_in, T* __restrict__ out, int64_t cols_out,
+                                      const int64_t* __restrict__ idx, int rows) {
+  const int64_t total = (int64_t)rows * cols_out;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols_out, j = i % cols_out;
+    out[i] = in[r * cols_in + idx[j]];
+  }
+}
+
 // out[t][:] = in[idx[t]][:]   (row resampling of a rows x cols matrix)
 template <typename T>
 __global__ void gather_rows_kernel(const T* __restrict__ in, T* __restrict__ out, const int64_t* __restrict__ idx, int rows,

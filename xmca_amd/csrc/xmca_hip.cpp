@@ -299,6 +299,40 @@ void center_field_impl(xmca_handle* h, int side, double* mean_out, double* std_o
   *n_nan_out = total;
 }
 
+// NaN-column handling of the constructor (array.py:191-197 `_set_no_nan_idx` / `_remove_nan_cols`) on the resident raw field:
+// keep_out[c] = 1 for columns without a NaN; the field is replaced by its kept columns (T x n_keep).
+template <typename TI>
+void compact_field_impl(xmca_handle* h, int side, int* keep_out, int64_t* n_keep_out) {
+  FieldData<TI>& f = fields_of<TI>(h)[side];
+  XMCA_CHECK(!f.has_im && !f.ext_re, XMCA_ERR_STATE, "compact_field: needs a real field owned by the library");
+  const int64_t N = f.N;
+  DevBuf<int> nans;
+  hipLaunchKernelGGL((column_nan_count_kernel<TI>), dim3((unsigned)ceil_div(N, (int64_t)256)), dim3(256), 0, h->st, f.re.get(), (int)f.T, N,
+                     nans.ensure((size_t)N));
+  XMCA_HIP(hipGetLastError());
+  std::vector<int> nh((size_t)N);
+  XMCA_HIP(hipMemcpyAsync(nh.data(), nans.get(), sizeof(int) * N, hipMemcpyDeviceToHost, h->st));
+  XMCA_HIP(hipStreamSynchronize(h->st));
+  std::vector<int64_t> idx;
+  idx.reserve((size_t)N);
+  for (int64_t c = 0; c < N; ++c) {
+    keep_out[c] = nh[(size_t)c] == 0 ? 1 : 0;
+    if (nh[(size_t)c] == 0) idx.push_back(c);
+  }
+  const int64_t nk = (int64_t)idx.size();
+  *n_keep_out = nk;
+  if (nk == N || nk == 0) return;     // nothing to drop / nothing left (the caller reports the latter its own way)
+  DevBuf<int64_t> idx_dev;
+  DevBuf<TI> out;
+  XMCA_HIP(hipMemcpyAsync(idx_dev.ensure((size_t)nk), idx.data(), sizeof(int64_t) * nk, hipMemcpyHostToDevice, h->st));
+  hipLaunchKernelGGL((gather_columns_kernel<TI>), ew_grid(f.T * nk), dim3(EW_BLOCK), 0, h->st, f.re.get(), N, out.ensure((size_t)(f.T * nk)), nk,
+                     idx_dev.get(), (int)f.T);
+  XMCA_HIP(hipGetLastError());
+  XMCA_HIP(hipStreamSynchronize(h->st));   // idx goes out of scope
+  f.re = std::move(out);
+  f.N = nk;
+}
+
 void fill_rot_outputs(const RotateResult& rr, bool cplx, double* R_out, double* Phi_out, double* nl, double* nr, int* iters) {
   const int p = rr.p;
   if (iters) *iters = rr.iters;
@@ -615,6 +649,16 @@ int xmca_center_field(xmca_handle* h, int side, double* mean_out, double* std_ou
   XMCA_CHECK(h->field_set[side] && mean_out && std_out && n_nan_out, XMCA_ERR_STATE, "center_field: set the field first");
   if (h->dtype == XMCA_F32) center_field_impl<float>(h, side, mean_out, std_out, n_nan_out);
   else center_field_impl<double>(h, side, mean_out, std_out, n_nan_out);
+  API_END(h)
+}
+
+int xmca_compact_field(xmca_handle* h, int side, int* keep_out, int64_t* n_keep_out) {
+  API_BEGIN(h)
+  XMCA_CHECK(side == 0 || side == 1, XMCA_ERR_INVALID, "compact_field: side must be 0 or 1");
+  XMCA_CHECK(h->field_set[side] && keep_out && n_keep_out, XMCA_ERR_STATE, "compact_field: set the field first");
+  if (h->dtype == XMCA_F32) compact_field_impl<float>(h, side, keep_out, n_keep_out);
+  else compact_field_impl<double>(h, side, keep_out, n_keep_out);
+  h->solved = false;
   API_END(h)
 }
 
