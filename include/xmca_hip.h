@@ -100,6 +100,10 @@ int xmca_center_field(xmca_handle* h, int side, double* mean_out, double* std_ou
  * (N ints), *n_keep_out their number; the resident field is replaced by those columns (T x n_keep, order kept).
  * With n_keep = 0 the field is left as it is (the caller raises the reference's error). */
 int xmca_compact_field(xmca_handle* h, int side, int* keep_out, int64_t* n_keep_out);
+/* Weights / normalisation of the constructor stage on the device (xmca/array.py:317-349 `apply_weights`, :351-365
+ * `normalize`): every column c of the resident real field of `side` is multiplied (divide = 0) or divided (divide = 1)
+ * by w[c]; w holds N values of the field's own element type, so the result equals the host operation bit for bit. */
+int xmca_scale_field(xmca_handle* h, int side, const void* w, int divide);
 /* Real plane of the resident field of `side` (T x N row-major, dtype XMCA_F32 / XMCA_F64 as it was set) -> host. */
 int xmca_get_field(xmca_handle* h, int side, void* out);
 

@@ -428,6 +428,35 @@ def test_device_preprocessing_drops_nan_columns_on_the_device(own_handle):
         assert pd[key].shape == pr[key].shape and np.array_equal(np.isnan(pd[key]), np.isnan(pr[key]))
 
 
+@pytest.mark.parametrize("own_handle", [False, True])
+def test_device_preprocessing_weights_and_normalize_on_the_device(own_handle):
+    """normalize() and per-column apply_weights() of a device-preprocessed model act on the resident fields
+    (xmca_scale_field); the model equals the host one (array.py:317-365)."""
+    from xmca_amd import _hip
+    sst, prcp = make_input("sst_prcp")
+    rng = np.random.default_rng(2)
+    ref = MCA(sst, prcp)
+    dev = MCA(sst, prcp, preprocess='device', **({"handle": _hip.Handle(0)} if own_handle else {}))
+    wl = rng.uniform(0.5, 1.5, ref._fields['left'].shape[1]).astype(sst.dtype)
+    wr = rng.uniform(0.5, 1.5, (1, ref._fields['right'].shape[1])).astype(prcp.dtype)
+    for m in (ref, dev):
+        m.normalize()
+        m.apply_weights(left=wl, right=wr)
+    assert dev._store_is_raw and dev._analysis['is_normalized']
+    dev.solve()
+    assert dev._store_is_raw                               # nothing came back to the host
+    ref.solve()
+    f32 = sst.dtype == np.float32
+    assert _rel(dev._singular_values[:8], ref._singular_values[:8]) < (1e-4 if f32 else 1e-10)
+    X, Xr = dev._get_X(), ref._get_X()
+    for key in ref._keys:
+        # (float32 input: the host's float32 column means carry ~3e-5 K of rounding at 300 K, the device's float64 ones do not)
+        assert X[key].dtype == Xr[key].dtype and _rel(X[key], Xr[key]) < (1e-4 if f32 else 1e-12)
+    full = MCA(sst, prcp, preprocess='device')
+    full.apply_weights(left=np.ones_like(ref._fields['left']))          # (T, N') weights: the host path, silently
+    assert not full._store_is_raw
+
+
 def test_device_preprocessing_falls_back_and_lost_ownership():
     bad = np.random.default_rng(0).standard_normal((30, 12))
     bad[:, :] = np.where(np.arange(12) % 2 == 0, np.nan, bad)     # half the columns NaN: fine

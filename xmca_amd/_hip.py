@@ -37,6 +37,7 @@ SIGNATURES = {
     "xmca_get_vectors": (_c_int, [_vp, _c_int, _vp, _c_i64, _c_int]),
     "xmca_center_field": (_c_int, [_vp, _c_int, _vp, _vp, ctypes.POINTER(_c_i64)]),
     "xmca_compact_field": (_c_int, [_vp, _c_int, _vp, ctypes.POINTER(_c_i64)]),
+    "xmca_scale_field": (_c_int, [_vp, _c_int, _vp, _c_int]),
     "xmca_get_field": (_c_int, [_vp, _c_int, _vp]),
     "xmca_bootstrap_begin": (_c_int, [_vp, _c_int]),
     "xmca_bootstrap_run": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_dbl, _vp, ctypes.POINTER(_c_int), _c_i64]),
@@ -258,6 +259,11 @@ class Handle:
         n_keep = _c_i64(0)
         self._check(self._lib.xmca_compact_field(self._h, side, _ptr(keep), ctypes.byref(n_keep)))
         return keep.astype(bool), int(n_keep.value)
+
+    def scale_field(self, side, w, divide=False):
+        """Multiplies (divides) column c of the resident real field of `side` by w[c]; `w` in the field's dtype."""
+        w = np.ascontiguousarray(w)
+        self._check(self._lib.xmca_scale_field(self._h, side, _ptr(w), int(bool(divide))))
 
     def get_field(self, side, shape, dtype):
         """Real plane of the resident field of `side` as a (T, N) array of `dtype` (the dtype it was set with)."""

@@ -32,6 +32,7 @@ class _RawField:
         self.keep = keep
         self.shape = (raw.shape[0], int(np.count_nonzero(keep)))
         self.dtype = raw.dtype
+        self.ops = []            # (divide, per-column factors) applied on the device after centering, in order
 
     @property
     def real(self):
@@ -39,6 +40,13 @@ class _RawField:
 
     def kept_columns(self):
         return self.raw if self.shape[1] == self.raw.shape[1] else self.raw[:, self.keep]
+
+    def centered(self):
+        """What the device holds, recomputed on the host."""
+        f = np.ascontiguousarray(remove_mean(self.kept_columns()))
+        for divide, w in self.ops:
+            f = f / w if divide else f * w
+        return f
 
 
 class MCA:
@@ -169,7 +177,7 @@ class MCA:
             store = {k: dev.get_field(side, self._fields_store[k].shape, self._fields_store[k].dtype)
                      for side, k in enumerate(self._keys)}
         else:
-            store = {k: np.ascontiguousarray(remove_mean(f.kept_columns())) for k, f in self._fields_store.items()}
+            store = {k: f.centered() for k, f in self._fields_store.items()}
         self._fields_store = store
         self._store_is_raw = False
 
@@ -287,15 +295,45 @@ class MCA:
     def apply_weights(self, left=None, right=None):
         """Multiply the (centered) fields by weights broadcastable to (T, N').  array.py:317-349"""
         weights = {'left': 1 if left is None else left, 'right': 1 if right is None else right}
+        if self._scale_on_device({k: weights[k] for k in self._keys}, divide=False):
+            return
         self._fields = {k: f * weights[k] for k, f in self._fields.items()}
 
     def normalize(self):
         """Divide every grid point's series by its standard deviation.  array.py:351-365"""
-        fields = self._fields
-        self._fields = {k: fields[k] / self._field_stds[k] for k in self._keys}
+        if not self._scale_on_device({k: self._field_stds[k] for k in self._keys}, divide=True):
+            fields = self._fields
+            self._fields = {k: fields[k] / self._field_stds[k] for k in self._keys}
         self._analysis['is_normalized'] = True
         self._analysis['is_coslat_corrected'] = False
         self._analysis['method'] = self._get_method_id()
+
+    def _scale_on_device(self, factors, divide):
+        """Device-preprocessed model whose fields are still resident: per-column factors (scalars, (N',) or (1, N')
+        arrays that do not change the dtype) are applied there.  False when the host path has to do it."""
+        if not self._store_is_raw:
+            return False
+        dev = self._device()
+        if not self._owns_device_fields(dev):
+            return False
+        cols = {}
+        for k, w in factors.items():
+            f = self._fields_store[k]
+            w = np.asarray(w)
+            if w.ndim > 2 or (w.ndim == 2 and w.shape[0] != 1) or np.iscomplexobj(w):
+                return False
+            orig = factors[k]
+            weak = isinstance(orig, (int, float)) and not isinstance(orig, np.generic)     # python scalars do not promote
+            if np.result_type(f.dtype, orig if weak else w.dtype) != f.dtype:
+                return False
+            try:
+                cols[k] = np.ascontiguousarray(np.broadcast_to(w.reshape(-1) if w.ndim else w, (f.shape[1],)), dtype=f.dtype)
+            except ValueError:
+                return False
+        for side, k in enumerate(self._keys):
+            dev.scale_field(side, cols[k], divide)
+            self._fields_store[k].ops.append((divide, cols[k]))
+        return True
 
     # ------------------------------------------------------------------------------------------
     # complexification on the host (only needed for extend != False, and lazily for the getters)

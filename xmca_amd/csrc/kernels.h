@@ -210,6 +210,16 @@ __global__ void gather_columns_kernel(const T* __restrict__ in, int64_t cols_in,
   }
 }
 
+// x[r][c] = x[r][c] * w[c]  or  x[r][c] / w[c]   (w already in the element type: the host's own operation, bit for bit)
+template <typename T>
+__global__ void scale_columns_kernel(T* __restrict__ x, int rows, int64_t cols, const T* __restrict__ w, int divide) {
+  const int64_t total = (int64_t)rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const T f = w[i % cols];
+    x[i] = divide ? x[i] / f : x[i] * f;
+  }
+}
+
 // out[t][:] = in[idx[t]][:]   (row resampling of a rows x cols matrix)
 template <typename T>
 __global__ void gather_rows_kernel(const T* __restrict__ in, T* __restrict__ out, const int64_t* __restrict__ idx, int rows,

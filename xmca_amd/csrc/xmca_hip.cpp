@@ -333,6 +333,18 @@ void compact_field_impl(xmca_handle* h, int side, int* keep_out, int64_t* n_keep
   f.N = nk;
 }
 
+// apply_weights / normalize of the constructor stage (array.py:317-365) on the resident centered field: one factor per column
+template <typename TI>
+void scale_field_impl(xmca_handle* h, int side, const void* w_host, int divide) {
+  FieldData<TI>& f = fields_of<TI>(h)[side];
+  XMCA_CHECK(!f.has_im && !f.ext_re, XMCA_ERR_STATE, "scale_field: needs a real field owned by the library");
+  DevBuf<TI> w;
+  XMCA_HIP(hipMemcpyAsync(w.ensure((size_t)f.N), w_host, sizeof(TI) * (size_t)f.N, hipMemcpyHostToDevice, h->st));
+  hipLaunchKernelGGL((scale_columns_kernel<TI>), ew_grid(f.T * f.N), dim3(EW_BLOCK), 0, h->st, f.re.get(), (int)f.T, f.N, w.get(), divide);
+  XMCA_HIP(hipGetLastError());
+  XMCA_HIP(hipStreamSynchronize(h->st));
+}
+
 void fill_rot_outputs(const RotateResult& rr, bool cplx, double* R_out, double* Phi_out, double* nl, double* nr, int* iters) {
   const int p = rr.p;
   if (iters) *iters = rr.iters;
@@ -658,6 +670,16 @@ int xmca_compact_field(xmca_handle* h, int side, int* keep_out, int64_t* n_keep_
   XMCA_CHECK(h->field_set[side] && keep_out && n_keep_out, XMCA_ERR_STATE, "compact_field: set the field first");
   if (h->dtype == XMCA_F32) compact_field_impl<float>(h, side, keep_out, n_keep_out);
   else compact_field_impl<double>(h, side, keep_out, n_keep_out);
+  h->solved = false;
+  API_END(h)
+}
+
+int xmca_scale_field(xmca_handle* h, int side, const void* w, int divide) {
+  API_BEGIN(h)
+  XMCA_CHECK(side == 0 || side == 1, XMCA_ERR_INVALID, "scale_field: side must be 0 or 1");
+  XMCA_CHECK(h->field_set[side] && w, XMCA_ERR_STATE, "scale_field: set the field first");
+  if (h->dtype == XMCA_F32) scale_field_impl<float>(h, side, w, divide);
+  else scale_field_impl<double>(h, side, w, divide);
   h->solved = false;
   API_END(h)
 }
