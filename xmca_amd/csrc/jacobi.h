@@ -159,6 +159,10 @@ inline void hermitian_evd(hipStream_t st, EvdWorkspace& ws, const double* Ar, co
   // stop after the first sweep that leaves no off-diagonal entry above 1e-10 * max|diag| behind: with the (at least
   // fast-linear, normally quadratic) convergence the next sweep would only confirm it
   EvdParams prm;
+  // eigenvalues only (rule_n): an eigenvalue is off by sum_j |g_ij|^2 / (lam_i - lam_j), second order in what is left -
+  // 1e-8 left behind bounds that by ~n 1e-16 lam_max for a spectrum without exact clusters, and the sweep that would
+  // push the vectors' first-order error down is not needed (C4 surrogates: 12 -> 11 sweeps)
+  if (!Zr) prm.tol = 1e-8;
   static const int mixed_mode = [] { const char* e = std::getenv("XMCA_JACOBI_MIXED"); return e ? std::atoi(e) : 0; }();   // 0 off, 1 on, 2 float only (tests)
   if (mixed_mode == 0 || !Zr || n < 384) {
     hermitian_evd_f64(st, ws, Ar, Ai, n, lda, lam_host, lam_dev, Zr, Zi, ldz, prm, info, force_tile);
