@@ -159,44 +159,74 @@ __global__ void center_columns_kernel(T* __restrict__ x, int rows, int64_t cols)
   for (int r = 0; r < rows; ++r) x[(int64_t)r * cols + c] = (T)((double)x[(int64_t)r * cols + c] - m);
 }
 
-// In-place column centering with statistics (the constructor's preprocessing, array.py:199-215): per column the mean,
-// the standard deviation (ddof = 0, two passes) and a NaN count; columns holding a NaN are left untouched.
+// Column passes of the constructor stage.  A thread per column alone leaves the chip empty (10^4 columns = 40 workgroups):
+// the rows are split into gridDim.y chunks, every (chunk, column) writes its partial result to part[chunk][c], and a
+// finishing kernel adds the chunks in a fixed order (no floating-point atomics: results do not depend on scheduling).
+constexpr int COL_CHUNKS = 32;
+
+// part_nan[chunk][c] = NaN entries, part_sum[chunk][c] = sum of column c over the rows of the chunk (part_sum may be null)
 template <typename T>
-__global__ void center_columns_stats_kernel(T* __restrict__ x, int rows, int64_t cols, double* __restrict__ mean,
-                                            double* __restrict__ stdev, int* __restrict__ nan_count) {
+__global__ void column_partial_sums_kernel(const T* __restrict__ x, int rows, int64_t cols, int* __restrict__ part_nan,
+                                           double* __restrict__ part_sum) {
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= cols) return;
+  const int per = (rows + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int r0 = (int)blockIdx.y * per, r1 = min(rows, r0 + per);
   double s = 0.0;
   int nans = 0;
-  for (int r = 0; r < rows; ++r) {
+  for (int r = r0; r < r1; ++r) {
     const double v = (double)x[(int64_t)r * cols + c];
     if (v != v) ++nans;
     s += v;
   }
-  nan_count[c] = nans;
-  const double m = s / rows;
-  mean[c] = m;
-  if (nans) { stdev[c] = m; return; }
-  double q = 0.0;
-  for (int r = 0; r < rows; ++r) {
-    const double d = (double)x[(int64_t)r * cols + c] - m;
-    q += d * d;
-    x[(int64_t)r * cols + c] = (T)d;
-  }
-  stdev[c] = sqrt(q / rows);
+  part_nan[(int64_t)blockIdx.y * cols + c] = nans;
+  if (part_sum) part_sum[(int64_t)blockIdx.y * cols + c] = s;
 }
 
-// nan_count[c] = number of NaN entries of column c (one thread per column, coalesced over columns)
-template <typename T>
-__global__ void column_nan_count_kernel(const T* __restrict__ x, int rows, int64_t cols, int* __restrict__ nan_count) {
+// nan_count[c] = sum over chunks; mean[c] = (sum over chunks) / rows   (mean may be null)
+__global__ void column_finish_sums_kernel(const int* __restrict__ part_nan, const double* __restrict__ part_sum, int chunks, int rows,
+                                          int64_t cols, int* __restrict__ nan_count, double* __restrict__ mean) {
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= cols) return;
-  int nans = 0;
-  for (int r = 0; r < rows; ++r) {
-    const T v = x[(int64_t)r * cols + c];
-    if (v != v) ++nans;
+  int n = 0;
+  double s = 0.0;
+  for (int k = 0; k < chunks; ++k) {
+    n += part_nan[(int64_t)k * cols + c];
+    if (part_sum) s += part_sum[(int64_t)k * cols + c];
   }
-  nan_count[c] = nans;
+  nan_count[c] = n;
+  if (mean) mean[c] = s / rows;
+}
+
+// x[r][c] -= mean[c] for the columns without NaN (a column holding one is left as it is); part_sq[chunk][c] = sum of squared deviations over the rows of the chunk
+template <typename T>
+__global__ void center_columns_chunk_kernel(T* __restrict__ x, int rows, int64_t cols, const double* __restrict__ mean,
+                                            const int* __restrict__ nan_count, double* __restrict__ part_sq) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  const int per = (rows + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int r0 = (int)blockIdx.y * per, r1 = min(rows, r0 + per);
+  double q = 0.0;
+  if (nan_count[c] == 0) {
+    const double m = mean[c];
+    for (int r = r0; r < r1; ++r) {
+      const double d = (double)x[(int64_t)r * cols + c] - m;
+      q += d * d;
+      x[(int64_t)r * cols + c] = (T)d;
+    }
+  }
+  part_sq[(int64_t)blockIdx.y * cols + c] = q;
+}
+
+// stdev[c] = sqrt(sum over chunks / rows)   (columns with NaN: the mean, as before)
+__global__ void column_finish_std_kernel(const double* __restrict__ part_sq, int chunks, int rows, int64_t cols,
+                                         const double* __restrict__ mean, const int* __restrict__ nan_count,
+                                         double* __restrict__ stdev) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  double q = 0.0;
+  for (int k = 0; k < chunks; ++k) q += part_sq[(int64_t)k * cols + c];
+  stdev[c] = nan_count[c] ? mean[c] : sqrt(q / rows);
 }
 
 // out[r][j] = in[r][idx[j]]   (column selection: rows x cols_in -> rows x cols_out)

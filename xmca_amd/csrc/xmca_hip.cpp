@@ -284,10 +284,20 @@ void center_field_impl(xmca_handle* h, int side, double* mean_out, double* std_o
   FieldData<TI>& f = fields_of<TI>(h)[side];
   XMCA_CHECK(!f.has_im && !f.ext_re, XMCA_ERR_STATE, "center_field: needs a real field owned by the library");
   const int64_t N = f.N;
-  DevBuf<double> mean, sd;
-  DevBuf<int> nans;
-  hipLaunchKernelGGL((center_columns_stats_kernel<TI>), dim3((unsigned)ceil_div(N, (int64_t)256)), dim3(256), 0, h->st, f.re.get(),
-                     (int)f.T, N, mean.ensure((size_t)N), sd.ensure((size_t)N), nans.ensure((size_t)N));
+  DevBuf<double> mean, sd, part_sum, part_sq;
+  DevBuf<int> nans, part_nan;
+  const int chunks = (int)std::min<int64_t>(COL_CHUNKS, f.T);
+  const dim3 grid2((unsigned)ceil_div(N, (int64_t)256), (unsigned)chunks), grid1((unsigned)ceil_div(N, (int64_t)256));
+  part_nan.ensure((size_t)chunks * N);
+  part_sum.ensure((size_t)chunks * N);
+  part_sq.ensure((size_t)chunks * N);
+  hipLaunchKernelGGL((column_partial_sums_kernel<TI>), grid2, dim3(256), 0, h->st, f.re.get(), (int)f.T, N, part_nan.get(), part_sum.get());
+  hipLaunchKernelGGL(column_finish_sums_kernel, grid1, dim3(256), 0, h->st, part_nan.get(), part_sum.get(), chunks, (int)f.T, N,
+                     nans.ensure((size_t)N), mean.ensure((size_t)N));
+  hipLaunchKernelGGL((center_columns_chunk_kernel<TI>), grid2, dim3(256), 0, h->st, f.re.get(), (int)f.T, N, mean.get(), nans.get(),
+                     part_sq.get());
+  hipLaunchKernelGGL(column_finish_std_kernel, grid1, dim3(256), 0, h->st, part_sq.get(), chunks, (int)f.T, N, mean.get(), nans.get(),
+                     sd.ensure((size_t)N));
   XMCA_HIP(hipGetLastError());
   std::vector<int> nh((size_t)N);
   XMCA_HIP(hipMemcpyAsync(mean_out, mean.get(), sizeof(double) * N, hipMemcpyDeviceToHost, h->st));
@@ -306,9 +316,13 @@ void compact_field_impl(xmca_handle* h, int side, int* keep_out, int64_t* n_keep
   FieldData<TI>& f = fields_of<TI>(h)[side];
   XMCA_CHECK(!f.has_im && !f.ext_re, XMCA_ERR_STATE, "compact_field: needs a real field owned by the library");
   const int64_t N = f.N;
-  DevBuf<int> nans;
-  hipLaunchKernelGGL((column_nan_count_kernel<TI>), dim3((unsigned)ceil_div(N, (int64_t)256)), dim3(256), 0, h->st, f.re.get(), (int)f.T, N,
-                     nans.ensure((size_t)N));
+  DevBuf<int> nans, part_nan;
+  const int chunks = (int)std::min<int64_t>(COL_CHUNKS, f.T);
+  part_nan.ensure((size_t)chunks * N);
+  hipLaunchKernelGGL((column_partial_sums_kernel<TI>), dim3((unsigned)ceil_div(N, (int64_t)256), (unsigned)chunks), dim3(256), 0, h->st,
+                     f.re.get(), (int)f.T, N, part_nan.get(), (double*)nullptr);
+  hipLaunchKernelGGL(column_finish_sums_kernel, dim3((unsigned)ceil_div(N, (int64_t)256)), dim3(256), 0, h->st, part_nan.get(),
+                     (const double*)nullptr, chunks, (int)f.T, N, nans.ensure((size_t)N), (double*)nullptr);
   XMCA_HIP(hipGetLastError());
   std::vector<int> nh((size_t)N);
   XMCA_HIP(hipMemcpyAsync(nh.data(), nans.get(), sizeof(int) * N, hipMemcpyDeviceToHost, h->st));
