@@ -162,14 +162,16 @@ def main():
         m.rotate(args.n_rot, args.power)
         t3 = time.perf_counter()
         pcs = m.pcs(args.n_rot)                     # X V on the resident field (device GEMM)
+        t3b = time.perf_counter()
+        Vh = m._V.head('left', args.n_rot)            # (leading modes only: the vectors stay on the device until read)
         t4 = time.perf_counter()
-        host_pcs = X @ m._V['left'][:, :args.n_rot]   # the reference's host product, for scale
+        host_pcs = X @ Vh                             # the reference's host product, for scale
         t5 = time.perf_counter()
         t6 = time.perf_counter()
         maps = m.homogeneous_patterns(args.n_rot)     # correlation maps (device GEMM + host p-values)
         t7 = time.perf_counter()
         extra["e2e_ms"] = {"ctor": 1e3 * (t1 - t0), "solve": 1e3 * (t2 - t1), "rotate": 1e3 * (t3 - t2),
-                           "upload_only": 1e3 * upload_s, "pcs_device": 1e3 * (t4 - t3), "pcs_host_product_only": 1e3 * (t5 - t4),
+                           "upload_only": 1e3 * upload_s, "pcs_device": 1e3 * (t3b - t3), "pcs_host_product_only": 1e3 * (t5 - t4),
                            "homogeneous_patterns": 1e3 * (t7 - t6)}
         del pcs, host_pcs, maps
         # the same through MCA(..., preprocess='device') (centering / mean / std on the GPU)

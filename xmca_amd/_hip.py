@@ -4,6 +4,7 @@ The product path has no CPU fallback: importing this module without the built
 library, or creating a handle without a visible MI355X, raises.
 """
 import ctypes
+import weakref
 import ctypes.util
 import os
 
@@ -171,9 +172,22 @@ class Handle:
             msg = self._lib.xmca_last_error(self._h)
             _raise(rc, msg.decode("utf-8", "replace") if msg else "xmca error %d" % rc)
 
+    # ---- result ownership -------------------------------------------------------------------
+    def hold_result(self, holder):
+        """`holder` (anything with `_materialize_vectors()`) still reads the vectors of the last solve from the device
+        on demand; it is asked to fetch them before anything invalidates that result."""
+        self._result_holder = weakref.ref(holder)
+
+    def release_result(self):
+        ref, self._result_holder = getattr(self, "_result_holder", None), None
+        holder = ref() if ref is not None else None
+        if holder is not None:
+            holder._materialize_vectors()
+
     # ---- fields -------------------------------------------------------------------------------
     def set_field(self, side, field):
         """field: T x N numpy array (real or complex, float32/float64 based)."""
+        self.release_result()
         self.fields_owner = None            # whoever uploads claims the resident fields afterwards (MCA._upload_fields)
         field = np.asarray(field)
         if field.ndim != 2:
@@ -190,19 +204,23 @@ class Handle:
 
     def set_field_device(self, side, re_ptr, im_ptr, T, N, dtype):
         """Adopt device pointers (e.g. torch tensors' data_ptr()); the caller keeps them alive."""
+        self.release_result()
         self._check(self._lib.xmca_set_field(self._h, side, _vp(re_ptr), _vp(im_ptr) if im_ptr else None, T, N,
                                              _np_dtype_code(dtype), DEVICE))
 
     def complexify(self, T):
+        self.release_result()
         ht = hilbert_imag_column(T)
         self._check(self._lib.xmca_complexify(self._h, _ptr(ht)))
 
     def decomplexify(self):
         """Back to the real resident fields (undoes `complexify` for the next solve)."""
+        self.release_result()
         self._check(self._lib.xmca_complexify(self._h, None))
 
     # ---- solve --------------------------------------------------------------------------------
     def solve(self, n_fields, n_vec=-1):
+        self.release_result()
         rank = _c_i64(0)
         self._check(self._lib.xmca_solve(self._h, n_fields, n_vec, ctypes.byref(rank)))
         return int(rank.value)
@@ -247,6 +265,7 @@ class Handle:
     def center_field(self, side, N):
         """Centers the resident (raw) field of `side` in place.  Returns (mean[N], std[N], number of NaN entries); when
         the last is not zero the field is unchanged."""
+        self.release_result()
         mean = np.empty(N, dtype=np.float64)
         std = np.empty(N, dtype=np.float64)
         n_nan = _c_i64(0)
@@ -255,6 +274,7 @@ class Handle:
 
     def compact_field(self, side, N):
         """Drops the NaN columns of the resident raw field of `side`.  Returns (keep mask[N], number of kept columns)."""
+        self.release_result()
         keep = np.empty(N, dtype=np.int32)
         n_keep = _c_i64(0)
         self._check(self._lib.xmca_compact_field(self._h, side, _ptr(keep), ctypes.byref(n_keep)))
@@ -262,6 +282,7 @@ class Handle:
 
     def scale_field(self, side, w, divide=False):
         """Multiplies (divides) column c of the resident real field of `side` by w[c]; `w` in the field's dtype."""
+        self.release_result()
         w = np.ascontiguousarray(w)
         self._check(self._lib.xmca_scale_field(self._h, side, _ptr(w), int(bool(divide))))
 
@@ -273,6 +294,7 @@ class Handle:
 
     def bootstrap_begin(self, n_fields):
         """Working copies of the resident fields for `bootstrap_run` (MCA.bootstrapping on the device)."""
+        self.release_result()
         self._check(self._lib.xmca_bootstrap_begin(self._h, n_fields))
 
     def bootstrap_run(self, T, complexify, idx_left, idx_right, rotated, p, power, tol, n_out):
@@ -317,6 +339,7 @@ class Handle:
 
     # ---- rule N -------------------------------------------------------------------------------
     def rule_n(self, T, Nx, Ny, n_fields, complexify, rotated, p, power, tol, run_begin, run_end, seed, dtype, n_out):
+        self.release_result()
         n = run_end - run_begin
         self.fields_owner = None            # the surrogates overwrite the resident fields
         spectra = np.zeros((max(n, 0), n_out), dtype=np.float64)

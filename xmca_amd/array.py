@@ -23,6 +23,54 @@ from .tools.text import boldify_str, secure_str, wrap_str
 _SCALINGS_MSG = ('The scaling option {:} is not valid. Please choose one of the following: None, eigen, std, max')
 
 
+class _LazyVectors(dict):
+    """`MCA._V` after solve(): (N', rank) singular vectors per field, fetched from the device when first read.  `head`
+    fetches only the leading modes while the full array has not been asked for."""
+
+    def __init__(self, dev, where, rank, dtype):
+        super().__init__({k: None for k in where})
+        self._dev, self._where, self._rank, self._dtype = dev, dict(where), rank, dtype
+        self._pending = set(where)
+
+    def _load(self, k):
+        if k in self._pending:
+            side, n_k = self._where[k]
+            dict.__setitem__(self, k, self._dev.vectors(side, self._rank, n_k, self._dtype).T)   # view of the mode-major result
+            self._pending.discard(k)
+
+    def materialize(self):
+        for k in list(self._pending):
+            self._load(k)
+
+    def head(self, k, m):
+        if k in self._pending:
+            side, n_k = self._where[k]
+            m = self._rank if m is None else min(m, self._rank)
+            if m < self._rank:
+                return self._dev.vectors(side, m, n_k, self._dtype).T
+            self._load(k)
+        return dict.__getitem__(self, k)[:, :m]
+
+    def __getitem__(self, k):
+        self._load(k)
+        return dict.__getitem__(self, k)
+
+    def __setitem__(self, k, v):
+        self._pending.discard(k)
+        dict.__setitem__(self, k, v)
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def items(self):
+        self.materialize()
+        return dict.items(self)
+
+    def values(self):
+        self.materialize()
+        return dict.values(self)
+
+
 class _RawField:
     """Stand-in for a field that was preprocessed on the device (MCA(..., preprocess='device')): the raw input, the
     mask of its NaN-free columns, and the shape / dtype the centered field has."""
@@ -409,6 +457,8 @@ class MCA:
         self._analysis['is_complex'] = complexify
         self._analysis['extend'] = extend
         self._analysis['theta_period'] = period
+        if isinstance(getattr(self, '_V', None), _LazyVectors):
+            del self._V                                              # vectors of an earlier solve still on the device: not wanted
 
         dev = self._device()
         if complexify and extend:
@@ -435,10 +485,10 @@ class MCA:
 
         real_dtype = _real_dtype(next(iter(self._fields_store.values())).dtype)
         singular_values = dev.singular_values(rank).astype(real_dtype, copy=False)
-        self._V = {}
-        for side, k in enumerate(self._keys):
-            n_k = self._fields_store[k].shape[1]
-            self._V[k] = dev.vectors(side, rank, n_k, real_dtype).T      # (N', rank) view of the mode-major result
+        # the vectors stay on the device until something reads them (233 MB at C2; pcs / eofs / rotate of a few modes
+        # fetch just those modes); anything that would invalidate them on the handle makes this model fetch them first
+        self._V = _LazyVectors(dev, {k: (side, self._fields_store[k].shape[1]) for side, k in enumerate(self._keys)}, rank, real_dtype)
+        dev.hold_result(self)
 
         self._singular_values = singular_values
         self._variance = singular_values
@@ -482,11 +532,17 @@ class MCA:
             return self._analysis['n_rot']
         return n.stop if isinstance(n, slice) else n
 
+    def _materialize_vectors(self):
+        """Called by the handle before the device result this model still reads from is overwritten."""
+        V = getattr(self, '_V', None)
+        if isinstance(V, _LazyVectors):
+            V.materialize()
+
     def _get_V(self, n=None, rotated=True):
         max_mode = self._max_mode(n, rotated)
         keep = self._get_slice(n)
         try:
-            V = {k: v[:, :max_mode] for k, v in self._V.items()}
+            V = {k: (self._V.head(k, max_mode) if isinstance(self._V, _LazyVectors) else self._V[k][:, :max_mode]) for k in self._V}
         except AttributeError:
             raise RuntimeError('Cannot retrieve singular vectors. Please call the method `solve` first.')
         for k in self._keys:
