@@ -493,3 +493,26 @@ def test_device_preprocessing_downloads_the_centered_field_on_demand():
     c.solve()                                              # and a real solve afterwards
     r.solve()
     assert _rel(c._singular_values[:8], r._singular_values[:8]) < 1e-10
+
+
+def test_singular_vectors_are_fetched_lazily_and_survive_other_models():
+    """`_V` stays on the device after solve(); reading the leading modes fetches only those, and a second model solving
+    on the same handle makes the first one fetch everything before its result is overwritten."""
+    fields = make_input("wide_both")
+    a = MCA(*fields)
+    a.solve()
+    assert set(a._V._pending) == {"left", "right"}
+    head = a._V.head("left", 3)
+    assert head.shape[1] == 3 and set(a._V._pending) == {"left", "right"}
+    e3 = a.eofs(3)                                          # public getter of three modes: still nothing fetched in full
+    assert set(a._V._pending) == {"left", "right"} and e3["left"].shape[-1] == 3
+    b = MCA(*make_input("small_both"))
+    b.solve()                                               # same default handle
+    assert not a._V._pending                                # a holds its own copy now
+    assert np.array_equal(a._V["left"][:, :3], head)
+    r = MCA(*fields)
+    r.solve()
+    assert _rel(a._singular_values, r._singular_values) < 1e-12
+    assert np.array_equal(a._V["right"], r._V["right"])    # the solver is deterministic
+    a.solve(complexify=True)                                # re-solving drops the pending fetch instead of doing it
+    assert np.iscomplexobj(a._V.head("left", 2))

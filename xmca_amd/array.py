@@ -539,6 +539,9 @@ class MCA:
             V.materialize()
 
     def _get_V(self, n=None, rotated=True):
+        # an unrotated model: the reference multiplies all `rank` modes by sqrt(s) I / sqrt(s) and reorders them by the
+        # (already descending) singular values - the identity; only the requested modes are touched here
+        rotated = rotated and self._analysis['is_rotated']
         max_mode = self._max_mode(n, rotated)
         keep = self._get_slice(n)
         try:
