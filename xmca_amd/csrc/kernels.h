@@ -148,17 +148,6 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(T* __restrict__ re,
   if (norms_out && threadIdx.x == 0) norms_out[r] = nrm;
 }
 
-// column means of a T x N row-major matrix, then subtraction.  One thread per column (coalesced across threads).
-template <typename T>
-__global__ void center_columns_kernel(T* __restrict__ x, int rows, int64_t cols) {
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
-  double s = 0.0;
-  for (int r = 0; r < rows; ++r) s += (double)x[(int64_t)r * cols + c];
-  const double m = s / rows;
-  for (int r = 0; r < rows; ++r) x[(int64_t)r * cols + c] = (T)((double)x[(int64_t)r * cols + c] - m);
-}
-
 // Column passes of the constructor stage.  A thread per column alone leaves the chip empty (10^4 columns = 40 workgroups):
 // the rows are split into gridDim.y chunks, every (chunk, column) writes its partial result to part[chunk][c], and a
 // finishing kernel adds the chunks in a fixed order (no floating-point atomics: results do not depend on scheduling).
@@ -196,6 +185,14 @@ __global__ void column_finish_sums_kernel(const int* __restrict__ part_nan, cons
   }
   nan_count[c] = n;
   if (mean) mean[c] = s / rows;
+}
+
+// x[r][c] -= mean[c]
+template <typename T>
+__global__ void subtract_column_means_kernel(T* __restrict__ x, int rows, int64_t cols, const double* __restrict__ mean) {
+  const int64_t total = (int64_t)rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    x[i] = (T)((double)x[i] - mean[i % cols]);
 }
 
 // x[r][c] -= mean[c] for the columns without NaN (a column holding one is left as it is); part_sq[chunk][c] = sum of squared deviations over the rows of the chunk

@@ -29,6 +29,8 @@ struct xmca_handle {
   // centered copies that are solved
   DevBuf<float> boot32[2], boot32_tmp;
   DevBuf<double> boot64[2], boot64_tmp;
+  DevBuf<int> center_nan;          // scratch of center_columns
+  DevBuf<double> center_sum;
   FieldData<float> bootf32[2];
   FieldData<double> bootf64[2];
   int64_t boot_T = 0, boot_N[2] = {0, 0};
@@ -279,6 +281,21 @@ void correlate_impl(xmca_handle* h, int side, const double* Y, int64_t T, int64_
   XMCA_HIP(hipStreamSynchronize(h->st));
 }
 
+// x <- x - column means (T x N row-major), what the MCA constructor does to every surrogate / replicate (array.py:117):
+// partial column sums over row chunks, means in a fixed order, one elementwise pass
+template <typename TI>
+void center_columns(xmca_handle* h, TI* x, int64_t T, int64_t N) {
+  const int chunks = (int)std::min<int64_t>(COL_CHUNKS, T);
+  const unsigned gx = (unsigned)ceil_div(N, (int64_t)256);
+  int* pn = h->center_nan.ensure((size_t)(chunks + 1) * N);
+  double* ps = h->center_sum.ensure((size_t)(chunks + 1) * N);
+  hipLaunchKernelGGL((column_partial_sums_kernel<TI>), dim3(gx, (unsigned)chunks), dim3(256), 0, h->st, x, (int)T, N, pn, ps);
+  hipLaunchKernelGGL(column_finish_sums_kernel, dim3(gx), dim3(256), 0, h->st, pn, ps, chunks, (int)T, N, pn + (size_t)chunks * N,
+                     ps + (size_t)chunks * N);
+  hipLaunchKernelGGL((subtract_column_means_kernel<TI>), ew_grid(T * N), dim3(EW_BLOCK), 0, h->st, x, (int)T, N, ps + (size_t)chunks * N);
+  XMCA_HIP(hipGetLastError());
+}
+
 template <typename TI>
 void center_field_impl(xmca_handle* h, int side, double* mean_out, double* std_out, int64_t* n_nan_out) {
   FieldData<TI>& f = fields_of<TI>(h)[side];
@@ -471,8 +488,8 @@ void rule_n_impl(xmca_handle* h, int64_t T, int64_t Nx, int64_t Ny, int n_fields
       TI* x = f[s].re.ensure((size_t)n);
       hipLaunchKernelGGL((philox_normal_kernel<TI>), ew_grid((n + 1) / 2), dim3(EW_BLOCK), 0, h->st, x, n, seed, (uint32_t)run,
                          (uint32_t)s);
-      hipLaunchKernelGGL((center_columns_kernel<TI>), dim3(ceil_div(Ns[s], 256)), dim3(256), 0, h->st, x, (int)T, Ns[s]);
       XMCA_HIP(hipGetLastError());
+      center_columns<TI>(h, x, T, Ns[s]);
     }
     h->tm.end();
     kept[run - run_begin] = runner.run(f, spectra + (run - run_begin) * n_out, n_out);
@@ -530,7 +547,7 @@ void bootstrap_run_impl(xmca_handle* h, const double* ht_host, const int64_t* id
     }
     f[s].T = T; f[s].N = N; f[s].has_im = false; f[s].ext_re = nullptr;
     XMCA_HIP(hipMemcpyAsync(f[s].re.ensure(n), W.get(), sizeof(TI) * n, hipMemcpyDeviceToDevice, h->st));
-    hipLaunchKernelGGL((center_columns_kernel<TI>), dim3(ceil_div(N, 256)), dim3(256), 0, h->st, f[s].re.get(), (int)T, N);   // MCA(...) ctor, array.py:117
+    center_columns<TI>(h, f[s].re.get(), T, N);   // MCA(...) ctor, array.py:117
     XMCA_HIP(hipGetLastError());
   }
   h->tm.end();
