@@ -167,6 +167,7 @@ def main():
         t4 = time.perf_counter()
         host_pcs = X @ Vh                             # the reference's host product, for scale
         t5 = time.perf_counter()
+        import scipy.stats                            # (the p-values come from scipy: keep its import out of the timing)
         t6 = time.perf_counter()
         maps = m.homogeneous_patterns(args.n_rot)     # correlation maps (device GEMM + host p-values)
         t7 = time.perf_counter()
