@@ -174,3 +174,43 @@ def test_shard_ranges_cover_all_runs():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             assert max(e - b for b, e in spans) - min(e - b for b, e in spans) <= 1
+
+
+def test_lazy_vectors_and_raw_field_stand_in():
+    """host logic of the device-resident state: `_LazyVectors` fetches leading modes / everything on demand and exactly
+    once; `_RawField` replays the device's preprocessing (NaN columns, centering, weights) on the host."""
+    from xmca_amd.array import _LazyVectors, _RawField
+
+    class FakeDev:
+        def __init__(self):
+            self.calls = []
+            self.Vt = {0: np.arange(5 * 7, dtype=np.float64).reshape(5, 7), 1: -np.arange(5 * 4, dtype=np.float64).reshape(5, 4)}
+
+        def vectors(self, side, n_modes, N, dtype):
+            self.calls.append((side, n_modes))
+            return self.Vt[side][:n_modes].astype(dtype)
+
+    dev = FakeDev()
+    V = _LazyVectors(dev, {"left": (0, 7), "right": (1, 4)}, 5, np.float64)
+    assert list(V) == ["left", "right"] and dev.calls == []
+    assert np.array_equal(V.head("left", 2), dev.Vt[0][:2].T) and dev.calls == [(0, 2)] and V._pending == {"left", "right"}
+    assert np.array_equal(V["left"], dev.Vt[0].T) and V._pending == {"right"}
+    assert np.array_equal(V.head("left", 3), dev.Vt[0][:3].T) and dev.calls == [(0, 2), (0, 5)]      # served from the host copy
+    assert np.array_equal(V.head("right", 9), dev.Vt[1].T) and not V._pending                       # more than rank: everything
+    assert [k for k, _ in V.items()] == ["left", "right"] and len(dev.calls) == 3
+    V2 = _LazyVectors(dev, {"left": (0, 7)}, 5, np.float64)
+    V2["left"] = np.zeros((7, 2))                                                                   # truncate(): assignment wins
+    assert not V2._pending and V2["left"].shape == (7, 2)
+
+    rng = np.random.default_rng(0)
+    raw = rng.standard_normal((20, 6))
+    raw[3, 1] = np.nan
+    raw[:, 4] = np.nan
+    keep = ~np.isnan(raw).any(axis=0)
+    f = _RawField(raw, keep)
+    assert f.shape == (20, 4) and f.dtype == raw.dtype and f.real is f and not np.iscomplexobj(f)
+    w = np.array([1.0, 2.0, 3.0, 4.0])
+    f.ops.append((True, np.nanstd(raw[:, keep], axis=0)))
+    f.ops.append((False, w))
+    want = (raw[:, keep] - raw[:, keep].mean(axis=0)) / raw[:, keep].std(axis=0) * w
+    assert np.allclose(f.centered(), want, rtol=1e-14, atol=1e-14)
