@@ -9,7 +9,8 @@
   (the PCIe-inclusive time through the MCA class is reported separately as `e2e_ms`, never as `value`).
 * N > 1: every rank processes its own replica of the workload on its own GPU (the path has no exchange step;
   SURVEY.md 8e) -> weak scaling; `value` = steps of all ranks / wall time.  The sharded rule_n (the only
-  collective of the path: one all_gather of the spectra) is exercised after the timed region.
+  collective of the path: one all_gather of the spectra) runs after the timed region on the C4 configuration and
+  is reported as `rule_n.surrogates_per_s` (all ranks together).
 * prints ONE JSON line on rank 0 with the driver's contract keys plus `roofline` (Gram GEMM, measured with
   hipEvents on the library's stream) and `cpu_baseline` (the numpy oracle timed on this host, N = 1 only).
 """
@@ -56,6 +57,7 @@ def main():
     ap.add_argument("--power", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rule-n", action="store_true")
+    ap.add_argument("--rule-n-runs", type=int, default=3, help="timed rule_n surrogates per GPU (C4 configuration)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -187,28 +189,27 @@ def main():
         del md
         extra["varimax_iterations"] = m._varimax_iterations
 
-    # ---- sharded rule_n (one all_gather of the spectra), bounded size ----
+    # ---- sharded rule_n (one all_gather of the spectra): the C4 configuration, a few runs per rank ----
     if not args.no_rule_n:
-        Tn, Nxn, Nyn = 1000, 4000, 3000
-        left = np.zeros((Tn, Nxn), dtype=np.float64)
+        Tn, Nxn, Nyn = 5000, 20000, 15000               # BASELINE.json configs[3]: rule_n on the synthetic MCA config
         model = MCA.__new__(MCA)                      # only the meta data rule_n reads is needed
         MCA.__init__(model)
         model._keys = ['left', 'right']
         model._n_observations = {'left': Tn, 'right': Tn}
         model._n_variables = {'left': Nxn, 'right': Nyn}
-        model._analysis.update({'is_bivariate': True, 'rank': Tn, 'n_rot': Tn})
+        model._analysis.update({'is_bivariate': True, 'is_complex': True, 'rank': Tn, 'n_rot': Tn})
         model._norm = {'left': np.ones(Tn), 'right': np.ones(Tn)}
         model._var_idx = np.arange(Tn)
         model._handle_override = h
-        n_runs = 2 * world
+        model.rule_n(world, seed=7)                   # one untimed surrogate per rank (workspaces, tile maps)
+        n_runs = args.rule_n_runs * world
         barrier()
         t0 = time.perf_counter()
         sp = model.rule_n(n_runs, seed=1)
         barrier()
         dt = time.perf_counter() - t0
-        extra["rule_n"] = {"config": "MCA T=1000 x (4000, 3000) f64, unrotated", "runs": n_runs,
-                           "surrogates_per_s": n_runs / dt, "shape": list(sp.shape)}
-        del left
+        extra["rule_n"] = {"config": "C4: MCA T=5000 x (20000, 15000) f64 surrogates, complexify=True, unrotated; %d runs per GPU" % args.rule_n_runs,
+                           "runs": n_runs, "surrogates_per_s": n_runs / dt, "shape": list(sp.shape)}
 
     # ---- CPU baseline: the numpy oracle (formula-identical to the reference) on this host, N = 1 only ----
     cpu = None
