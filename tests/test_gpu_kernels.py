@@ -172,6 +172,40 @@ def test_eigh_single_and_mixed_precision_modes(mode, cplx):
     assert out["lam"] < tol[0] and out["orth"] < tol[1] and out["res"] < tol[2], out
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_eigh_randomised_shapes_and_spectra(hip, seed):
+    """sizes around the tile boundaries, real / complex, flat / graded / rank-deficient / indefinite / spiked spectra and
+    scales from 1e-6 to 1e6 (the generator of scripts/eigh_stress.py, fewer trials)."""
+    rng = np.random.default_rng(seed)
+    sizes = [1, 2, 31, 33, 63, 64, 65, 127, 129, 191, 193, 257, 320, 385, 500]
+    for trial in range(14):
+        n = int(rng.choice(sizes))
+        cplx = bool(rng.integers(2))
+        kind = rng.choice(["flat", "graded", "deficient", "indefinite", "spiked"])
+        Q = rng.standard_normal((n, n)) + (1j * rng.standard_normal((n, n)) if cplx else 0)
+        Q, _ = np.linalg.qr(Q)
+        if kind == "flat":
+            lam = rng.uniform(0.1, 1.0, n)
+        elif kind == "graded":
+            lam = np.logspace(0, -rng.uniform(3, 13), n)
+        elif kind == "deficient":
+            lam = np.where(np.arange(n) < max(1, n // 3), rng.uniform(0.1, 1, n), 0.0)
+        elif kind == "indefinite":
+            lam = rng.standard_normal(n) * np.logspace(0, -rng.uniform(0, 8), n)
+        else:
+            lam = np.concatenate([rng.uniform(1e4, 1e6, min(5, n)), rng.uniform(0.5, 1.0, max(n - 5, 0))])[:n]
+        A = (Q * lam) @ Q.conj().T
+        A = (A + A.conj().T) / 2 * 10.0 ** rng.integers(-6, 7)
+        w, U = hip.eigh(A)
+        ref = np.linalg.eigvalsh(A)[::-1]
+        scale = np.abs(ref).max()
+        ctx = (n, cplx, str(kind), hip.last_eigh_info)
+        assert np.all(np.diff(w) <= 0), ctx
+        assert np.max(np.abs(w - ref)) < 2e-11 * scale, ctx
+        assert np.max(np.abs(U.conj().T @ U - np.eye(n))) < 2e-10, ctx
+        assert np.max(np.abs(A @ U - U * w)) < 2e-10 * scale, ctx
+
+
 def test_eigh_nan_is_an_error(hip):
     G = np.eye(40)
     G[3, 5] = G[5, 3] = np.nan
