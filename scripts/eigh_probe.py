@@ -39,6 +39,10 @@ elif kind == "smooth":  # Gram matrix of a smooth red-noise field (AR(1) in time
     X = pcs @ modes + 1e-3 * rng.standard_normal((T, N))
     X -= X.mean(axis=0)
     A = X @ X.T
+elif kind == "deficient":   # Gram matrix of rank T/2 (as the complexified T x T Gram of an analytic signal is)
+    T, N = 2920, 1460
+    X = rng.standard_normal((T, N))
+    A = X @ X.T
 elif kind == "cplx":   # Hermitian, analytic-signal-like
     T, N = 2501, 6000
     X = rng.standard_normal((T, N)) + 1j * rng.standard_normal((T, N))
