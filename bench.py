@@ -1,22 +1,32 @@
 #!/usr/bin/env python3
 """Headline benchmark: MCA.solve() + MCA.rotate() on the BASELINE.json configuration C2
-(synthetic EOF, T = 2920 x N = 10 000 grid points, float64, rotate(n_rot=10, power=1)), one MI355X per rank.
+(synthetic EOF, T = 2920 x N = 10 000 grid points, float64, rotate(n_rot=10, power=1)), one MI355X per rank, and the
+run-sharded rule_n of configuration C4 (surrogates/s over all ranks).
 
     python bench.py --gpus N --steps K --warmup W
 
-* a "step" = one pass of the hot path: device solve (Gram GEMM, eigensolver, back-projection of all `rank`
-  modes) + Varimax/Promax rotation, with the centered field ALREADY RESIDENT in HBM when the timed region starts
-  (the PCIe-inclusive time through the MCA class is reported separately as `e2e_ms`, never as `value`).
-* N > 1: every rank processes its own replica of the workload on its own GPU (the path has no exchange step;
-  SURVEY.md 8e) -> weak scaling; `value` = steps of all ranks / wall time.  The sharded rule_n (the only
-  collective of the path: one all_gather of the spectra) runs after the timed region on the C4 configuration and
-  is reported as `rule_n.surrogates_per_s` (all ranks together).
-* prints ONE JSON line on rank 0 with the driver's contract keys plus `roofline` (Gram GEMM, measured with
-  hipEvents on the library's stream) and `cpu_baseline` (the numpy oracle timed on this host, N = 1 only).
+* a "step" = one pass of the hot path: device solve (Gram GEMM, eigensolver, back-projection of all `rank` modes) +
+  Varimax/Promax rotation, with the centered field ALREADY RESIDENT in HBM when the timed region starts (the
+  PCIe-inclusive time through the MCA class is reported separately as `e2e_ms`, never as `value`).
+* --gpus N > 1 without a torch.distributed environment: bench.py launches itself as N ranks (torch.distributed.run,
+  127.0.0.1), one GPU each; under a launcher (WORLD_SIZE set) it is one of the ranks and WORLD_SIZE must equal --gpus.
+  Every rank processes its own replica of the workload (the path has no exchange step) -> weak scaling;
+  `value` = steps of all ranks / max-over-ranks wall time.  The sharded rule_n (the only collective of the path: one
+  all_gather of the spectra) runs after the timed region on the C4 configuration and is reported as
+  `rule_n.surrogates_per_s` (all ranks together).  XMCA_BENCH_SHARE_GPU=1 puts every rank on GPU 0 with the gloo
+  backend (RCCL refuses two ranks on one device) - the way the multi-rank flow is exercised on a 1-GPU box.
+* prints ONE JSON line on rank 0 with the driver's contract keys plus
+    `roofline`       the DOMINANT kernel of the step, jacobi_fused_round_kernel (f64 MFMA bound): algorithmic flops of one
+                     round / average launch duration, hipEvents on the library's stream around the rounds of every sweep
+                     of the timed region;
+    `roofline_gemm`  the covariance (Gram) GEMM, the kernel north_star quotes an MFMA utilisation for;
+    `cpu_baseline`   the numpy oracle on this host (N = 1 only): one C2 solve()+rotate() and one reduced C4 surrogate.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -46,6 +56,32 @@ def device_step(h, T, N, n_rot, power, dtype):
     return sig, out
 
 
+def launch_ranks(args):
+    """--gpus N > 1 outside a launcher: re-run this script as N ranks (one per GPU) and pass rank 0's line through."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rule_n_model(MCA, h, Tn, Nxn, Nyn):
+    """only the meta data rule_n reads is needed (array.py:1744-1749)"""
+    model = MCA.__new__(MCA)
+    MCA.__init__(model)
+    model._keys = ['left', 'right']
+    model._n_observations = {'left': Tn, 'right': Tn}
+    model._n_variables = {'left': Nxn, 'right': Nyn}
+    model._analysis.update({'is_bivariate': True, 'is_complex': True, 'rank': Tn, 'n_rot': Tn})
+    model._norm = {'left': np.ones(Tn), 'right': np.ones(Tn)}
+    model._var_idx = np.arange(Tn)
+    model._handle_override = h
+    return model
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,18 +93,27 @@ def main():
     ap.add_argument("--power", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rule-n", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--rule-n-runs", type=int, default=3, help="timed rule_n surrogates per GPU (C4 configuration)")
+    ap.add_argument("--rule-n-rotated", action="store_true",
+                    help="also time the ROTATED C4 variant (n_rot=20, power=4) and report its dropped runs")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     import torch
     td = None
-    # XMCA_BENCH_BACKEND=gloo (+ XMCA_BENCH_SHARE_GPU=1: every rank on GPU 0) exercises the multi-rank flow on a 1-GPU box
-    backend = os.environ.get("XMCA_BENCH_BACKEND", "nccl")
-    if os.environ.get("XMCA_BENCH_SHARE_GPU") == "1":
+    share = os.environ.get("XMCA_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("XMCA_BENCH_BACKEND", "gloo" if share else "nccl")
+    if share:
         local_rank = 0
+    elif world > torch.cuda.device_count():
+        sys.exit("bench.py: %d ranks but %d GPUs visible (XMCA_BENCH_SHARE_GPU=1 shares GPU 0)" % (world, torch.cuda.device_count()))
     if world > 1:
         import torch.distributed as td
         torch.cuda.set_device(local_rank)
@@ -104,7 +149,10 @@ def main():
         sig, out = device_step(h, T, N, args.n_rot, args.power, X.dtype)
     barrier()
     elapsed = time.perf_counter() - t0
-    stages = {k: v / args.steps for k, v in h.timings().items()}
+    timings = h.timings()
+    round_ms = timings.pop("jacobi_round_kernel_ms", 0.0)
+    round_launches = timings.pop("jacobi_round_kernel_launches", 0.0)
+    stages = {k: v / args.steps for k, v in timings.items()}
     stages["eigh_info"] = h.solve_info()[0]
     if td is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
@@ -113,37 +161,37 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * args.steps / elapsed
 
-    # ---- roofline of the covariance (Gram) GEMM, measured live with hipEvents on the library's stream ----
-    # achieved = algorithmic flops T(T+1)N of one Gram product / average duration of the MFMA kernel launch
-    # (hipEvents recorded around that launch on the library's stream); the product including its split-K reduction
-    # is reported next to it.  traffic: HBM-side bytes per launch of the same kernel on the same workload from
-    # rocprofv3 PMC passes (profiles/r01_pmc_gram_c2.json: (2*FETCH_SIZE + WRITE_SIZE) * 1024, gfx950 correction).
+    # ---- roofline of the dominant kernel: one launch of jacobi_fused_round_kernel per round of the block-Jacobi sweeps ----
+    # algorithmic work of a round with S pair slots of NT x NT tiles: every upper off-diagonal tile G[P,Q] <- J_P^H G J_Q
+    # (two NT^3 products = 4 NT^3 flop) and every eigenvector tile Z[P,c] <- J_P^H Z (one product, 2 NT^3 flop); every
+    # tile is read once and written once.  Duration: hipEvents on the library's stream around the rounds of
+    # every sweep of the timed region (jacobi_impl.inc), divided by the number of launches.
+    info = stages["eigh_info"]
+    roofline = None
+    if round_launches > 0 and info.get("slots", 0) > 1:
+        S, nt = info["slots"], info["tile"]
+        flops_round = (S * (S - 1) // 2) * 4.0 * nt ** 3 + S * S * 2.0 * nt ** 3
+        bytes_round = 2.0 * 8.0 * nt * nt * (S * (S + 1) // 2 + S * S)
+        us_round = 1e3 * round_ms / round_launches
+        tf = flops_round / us_round / 1e6
+        roofline = {"kernel": "jacobi_fused_round_kernel<%d,real> (v_mfma_f64_16x16x4_f64; one launch per round, %d rounds per sweep)"
+                              % (nt, 2 * S - 1),
+                    "bound": "mfma", "achieved": tf, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / F64_MFMA_PEAK_TF,
+                    "traffic": None,      # HBM bytes per launch come from separate rocprofv3 --pmc passes: profiles/r02_pmc_*.json
+                    "flops_per_launch": flops_round, "avg_launch_us": us_round, "launches_per_step": round_launches / args.steps,
+                    "share_of_step": round_ms / args.steps / ms_per_step,
+                    "algorithmic_bytes": bytes_round, "algorithmic_GBs": bytes_round / us_round / 1e3,
+                    "frac_of_hbm_peak": bytes_round / us_round / 1e3 / 8000.0}
+
+    # ---- the covariance (Gram) GEMM, measured live with hipEvents on the library's stream ----
     g = h.bench_gram(0, 5)
     gram_tf = g["flops"] / (g["kernel_ms"] * 1e-3) / 1e12
-    default_workload = (T, N) == (2920, 10_000)
-    roofline = {"kernel": "gemm_kernel<f64> (Gram X X^T, v_mfma_f64_16x16x4_f64, upper block triangle)", "bound": "mfma",
-                "achieved": gram_tf, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": gram_tf / F64_MFMA_PEAK_TF,
-                "traffic": 2.456e9 if default_workload else None, "flops_per_launch": g["flops"],
-                "avg_launch_ms": g["kernel_ms"], "product_ms_incl_splitk_reduce": g["avg_ms"],
-                "algorithmic_bytes": 8.0 * (T * N + T * T)}
+    roofline_gemm = {"kernel": "gemm_kernel<f64> (Gram X X^T, v_mfma_f64_16x16x4_f64, upper block triangle)", "bound": "mfma",
+                     "achieved": gram_tf, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": gram_tf / F64_MFMA_PEAK_TF,
+                     "traffic": None, "flops_per_launch": g["flops"], "avg_launch_ms": g["kernel_ms"],
+                     "product_ms_incl_reduction": g["avg_ms"], "algorithmic_bytes": 8.0 * (T * N + T * T)}
 
     extra = {}
-    # ---- the T x T eigensolver ("latency bound; report ms and achieved GF/s informally") ----
-    # one launch of jacobi_fused_round_kernel per round; per round every upper tile of G (two 64^3 products) and every
-    # eigenvector tile (one product) is read and written once
-    info = stages["eigh_info"]
-    if info.get("slots", 0) > 1 and info.get("sweeps", 0) > 0:
-        S, nt = info["slots"], info["tile"]
-        rounds = info["sweeps"] * (2 * S - 1)
-        flops_round = (S * (S - 1) // 2) * 2 * 2.0 * nt ** 3 + S * S * 2.0 * nt ** 3
-        bytes_round = 2.0 * 8.0 * nt * nt * (S * (S + 1) // 2 + S * S)
-        us_round = 1e3 * stages["eigh"] / rounds
-        extra["eigensolver"] = {"kernel": "jacobi_fused_round_kernel<64,real> (one launch per round)", "rounds": rounds,
-                                "us_per_round_incl_init_and_gather": us_round,
-                                "algorithmic_flops_per_round": flops_round, "achieved_TFLOPs": flops_round / us_round / 1e6,
-                                "frac_of_f64_mfma_peak": flops_round / us_round / 1e6 / F64_MFMA_PEAK_TF,
-                                "algorithmic_bytes_per_round": bytes_round, "achieved_GBs": bytes_round / us_round / 1e3,
-                                "frac_of_hbm_peak": bytes_round / us_round / 1e3 / 8000.0}
     if stages.get("varimax") and out.get("n_iter"):
         extra["varimax_us_per_iteration"] = 1e3 * stages["varimax"] / out["n_iter"]
     # cheap self-check of the timed result (full parity against the oracle is in cpu_baseline/parity and tests/)
@@ -155,52 +203,37 @@ def main():
         "orthonormality_first_modes": float(np.max(np.abs(Vt @ Vt.T - np.eye(args.n_rot)))),
     }
     # ---- PCIe-inclusive end-to-end through the drop-in class (reported, never `value`) ----
-    if rank == 0:
-        t0 = time.perf_counter()
-        m = MCA(X, handle=h)
-        t1 = time.perf_counter()
-        m.solve()
-        t2 = time.perf_counter()
-        m.rotate(args.n_rot, args.power)
+    if rank == 0 and not args.no_e2e:
+        Xraw = X + 3.0                                    # an uncentered input, like a user's
+
+        def through_class(preprocess):
+            t0 = time.perf_counter()
+            m = MCA(Xraw, handle=h, preprocess=preprocess)
+            t1 = time.perf_counter()
+            m.solve()
+            t2 = time.perf_counter()
+            m.rotate(args.n_rot, args.power)
+            t3 = time.perf_counter()
+            return m, {"ctor": 1e3 * (t1 - t0), "solve": 1e3 * (t2 - t1), "rotate": 1e3 * (t3 - t2), "total": 1e3 * (t3 - t0)}
+        through_class('device')                           # (first use of the preprocessing kernels)
+        m, extra["e2e_ms"] = through_class('device')      # the default path of MCA(X): raw field up, centered on the GPU
+        extra["e2e_ms"]["path"] = "MCA(X) -> solve() -> rotate(): upload of the raw field + device centering + device solve/rotate"
         t3 = time.perf_counter()
         pcs = m.pcs(args.n_rot)                     # X V on the resident field (device GEMM)
         t3b = time.perf_counter()
-        Vh = m._V.head('left', args.n_rot)            # (leading modes only: the vectors stay on the device until read)
-        t4 = time.perf_counter()
-        host_pcs = X @ Vh                             # the reference's host product, for scale
-        t5 = time.perf_counter()
         import scipy.stats                            # (the p-values come from scipy: keep its import out of the timing)
         t6 = time.perf_counter()
         maps = m.homogeneous_patterns(args.n_rot)     # correlation maps (device GEMM + host p-values)
         t7 = time.perf_counter()
-        extra["e2e_ms"] = {"ctor": 1e3 * (t1 - t0), "solve": 1e3 * (t2 - t1), "rotate": 1e3 * (t3 - t2),
-                           "upload_only": 1e3 * upload_s, "pcs_device": 1e3 * (t3b - t3), "pcs_host_product_only": 1e3 * (t5 - t4),
-                           "homogeneous_patterns": 1e3 * (t7 - t6)}
-        del pcs, host_pcs, maps
-        # the same through MCA(..., preprocess='device') (centering / mean / std on the GPU)
-        t0 = time.perf_counter()
-        md = MCA(X, handle=h, preprocess='device')
-        t1 = time.perf_counter()
-        md.solve()
-        t2 = time.perf_counter()
-        md.rotate(args.n_rot, args.power)
-        t3 = time.perf_counter()
-        extra["e2e_device_preprocess_ms"] = {"ctor": 1e3 * (t1 - t0), "solve": 1e3 * (t2 - t1), "rotate": 1e3 * (t3 - t2)}
-        del md
+        extra["e2e_ms"].update({"upload_only": 1e3 * upload_s, "pcs": 1e3 * (t3b - t3), "homogeneous_patterns": 1e3 * (t7 - t6)})
         extra["varimax_iterations"] = m._varimax_iterations
+        del pcs, maps, m
+        _, extra["e2e_host_preprocess_ms"] = through_class('host')   # bit-compatible numpy constructor (preprocess='host')
 
     # ---- sharded rule_n (one all_gather of the spectra): the C4 configuration, a few runs per rank ----
     if not args.no_rule_n:
         Tn, Nxn, Nyn = 5000, 20000, 15000               # BASELINE.json configs[3]: rule_n on the synthetic MCA config
-        model = MCA.__new__(MCA)                      # only the meta data rule_n reads is needed
-        MCA.__init__(model)
-        model._keys = ['left', 'right']
-        model._n_observations = {'left': Tn, 'right': Tn}
-        model._n_variables = {'left': Nxn, 'right': Nyn}
-        model._analysis.update({'is_bivariate': True, 'is_complex': True, 'rank': Tn, 'n_rot': Tn})
-        model._norm = {'left': np.ones(Tn), 'right': np.ones(Tn)}
-        model._var_idx = np.arange(Tn)
-        model._handle_override = h
+        model = rule_n_model(MCA, h, Tn, Nxn, Nyn)
         model.rule_n(world, seed=7)                   # one untimed surrogate per rank (workspaces, tile maps)
         n_runs = args.rule_n_runs * world
         barrier()
@@ -208,8 +241,27 @@ def main():
         sp = model.rule_n(n_runs, seed=1)
         barrier()
         dt = time.perf_counter() - t0
-        extra["rule_n"] = {"config": "C4: MCA T=5000 x (20000, 15000) f64 surrogates, complexify=True, unrotated; %d runs per GPU" % args.rule_n_runs,
-                           "runs": n_runs, "surrogates_per_s": n_runs / dt, "shape": list(sp.shape)}
+        if td is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
+            td.all_reduce(tt, op=td.ReduceOp.MAX)
+            dt = float(tt.item())
+        extra["rule_n"] = {"config": "C4: MCA T=%d x (%d, %d) f64 surrogates, complexify=True, unrotated; %d runs per GPU, "
+                                     "run-sharded, one all_gather (%s)" % (Tn, Nxn, Nyn, args.rule_n_runs, backend if world > 1 else "single rank"),
+                           "runs": n_runs, "surrogates_per_s": n_runs / dt, "shape": list(sp.shape),
+                           "spectrum_sum_check": float(abs(sp.sum(axis=0) / model._get_variance().sum() - 1).max())}
+        if args.rule_n_rotated:
+            model._analysis.update({'is_rotated': True, 'n_rot': 20, 'power': 4})
+            model._norm = {'left': np.ones(20), 'right': np.ones(20)}
+            model._var_idx = np.arange(20)
+            barrier()
+            t0 = time.perf_counter()
+            spr = model.rule_n(n_runs, seed=1)
+            barrier()
+            dtr = time.perf_counter() - t0
+            extra["rule_n_rotated"] = {"config": "C4 rotated: n_rot=20, power=4 (complex white noise: Varimax rarely converges in "
+                                                 "1000 iterations; the reference drops those runs, array.py:1759-1763)",
+                                       "runs": n_runs, "kept": int(spr.shape[1]), "dropped": int(n_runs - spr.shape[1]),
+                                       "surrogates_per_s": n_runs / dtr}
 
     # ---- CPU baseline: the numpy oracle (formula-identical to the reference) on this host, N = 1 only ----
     cpu = None
@@ -226,20 +278,41 @@ def main():
                "solve_ms": 1e3 * (t1 - t0), "rotate_ms": 1e3 * (t2 - t1), "varimax_iterations": int(r["n_iter"])}
         # parity of this very run (sign-aligned leading loadings, singular values)
         ks = 20
+        V10 = o["V"][0][:, :args.n_rot]
+        ph = np.sign(np.sum(V10 * Vt.T, axis=0))
         extra["parity"] = {"sigma_rel_err_first20": float(np.max(np.abs(sig[:ks] - o["singular_values"][:ks])
                                                                  / o["singular_values"][:ks])),
+                           "sigma_rel_err_all_nonnull": float(np.max(np.abs(sig[:T - 1] - o["singular_values"][:T - 1])
+                                                                     / o["singular_values"][:T - 1])),
+                           "loadings_max_err_first_modes": float(np.max(np.abs(Vt.T * ph - V10)) / np.max(np.abs(V10))),
                            "iterations_equal": bool(out["n_iter"] == r["n_iter"])}
+        del o, r
+        if not args.no_rule_n:
+            # rule_n CPU baseline: ONE surrogate of the C4 body at a quarter of every dimension (T = 1250 x (5000, 3750),
+            # complexify): normals, constructor, solve - the reference's per-run work (array.py:1755-1764).  gesdd costs
+            # ~T^2 N, so a full-size surrogate is ~64 x this sample (SURVEY.md 6 measured 275 s for the full solve).
+            Tq, Nxq, Nyq = 1250, 5000, 3750
+            t0 = time.perf_counter()
+            data = [np.random.standard_normal([Tq, Nxq]), np.random.standard_normal([Tq, Nyq])]
+            om = O.OracleModel(*data)
+            om.solve(complexify=True)
+            om.variance()
+            dtq = time.perf_counter() - t0
+            cpu["rule_n"] = {"sample": "1 surrogate at T=%d x (%d, %d), complexify (1/4 of every C4 dimension)" % (Tq, Nxq, Nyq),
+                             "seconds": dtq, "extrapolated_full_size_seconds": 64.0 * dtq,
+                             "extrapolation": "x64 (gesdd ~ T^2 N)", "surrogates_per_s_full_size": 1.0 / (64.0 * dtq)}
 
     if rank == 0:
         line = {
-            "metric": "MCA solve+rotate throughput (ms_per_step = solve+rotate wall-clock, ms)",
+            "metric": "MCA solve+rotate throughput (ms_per_step = solve+rotate wall-clock, ms); rule_n surrogates/s in `rule_n`",
             "value": value, "unit": "solve+rotate/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C2: synthetic EOF T=%d x N=%d float64 (generator A), solve() + rotate(n_rot=%d, power=%d)"
                                    % (T, N, args.n_rot, args.power),
-                       "parallelism": "replicas x%d (rule_n run-sharding exercised separately)" % world},
-            "stages_ms": stages, "roofline": roofline, "cpu_baseline": cpu,
+                       "parallelism": "replicas x%d (solve/rotate do not shard); rule_n run-sharded x%d" % (world, world)},
+            "rule_n_surrogates_per_s": extra.get("rule_n", {}).get("surrogates_per_s"),
+            "stages_ms": stages, "roofline": roofline, "roofline_gemm": roofline_gemm, "cpu_baseline": cpu,
         }
         line.update(extra)
         print(json.dumps(line))

@@ -40,6 +40,9 @@ typedef struct xmca_handle xmca_handle;
 
 /* library / device management ------------------------------------------------------------------------- */
 const char* xmca_version(void);
+/* Number of this header's ABI (XMCA_ABI_VERSION): the binding refuses a library built from another revision. */
+#define XMCA_ABI_VERSION 3
+int xmca_abi_version(void);
 int xmca_device_count(void);
 int xmca_create(int device, xmca_handle** out);
 void xmca_destroy(xmca_handle* h);
@@ -129,13 +132,15 @@ int xmca_get_solve_info(xmca_handle* h, int* info, int n);
  * float64, interleaved complex when is_complex), as built by MCA.rotate (array.py:821-822).
  *   n_left        rows belonging to the left field (array.py:818, :827-828)
  *   varimax_only  1: stop after Varimax (tools.rotation.varimax), 0: full Promax (also for power = 1)
+ *   gamma         the `gamma` of tools.rotation.varimax (rotation.py:15, :56-57): 1 = Varimax (what promax / MCA.rotate
+ *                 use), 0 = Quartimax; any real value is accepted
  *   B_out         NULL or N x p rotated loadings
  *   R_out/Phi_out p x p (interleaved complex when is_complex); norm_left/right: p column norms of the two
  *                 row blocks of the rotated loadings (array.py:827-828); iters_out: Varimax iterations run.
  * Returns XMCA_ERR_NOT_CONVERGED when max_iter iterations did not satisfy |d - d_old| / d < tol. */
 int xmca_rotate_loadings(xmca_handle* h, const double* L, int64_t N, int64_t n_left, int p, int is_complex, int power,
-                         double tol, int max_iter, int varimax_only, double* B_out, double* R_out, double* Phi_out,
-                         double* norm_left, double* norm_right, int* iters_out);
+                         double tol, int max_iter, int varimax_only, double gamma, double* B_out, double* R_out,
+                         double* Phi_out, double* norm_left, double* norm_right, int* iters_out);
 
 /* MCA.rule_n surrogate loop (xmca/array.py:1753-1765) for runs [run_begin, run_end): N(0,1) surrogates
  * (Philox4x32-10 keyed by seed, run, side) generated on the device, centered, optionally complexified
@@ -152,7 +157,10 @@ int xmca_rule_n(xmca_handle* h, int64_t T, int64_t Nx, int64_t Ny, int n_fields,
 /* Surrogate generator on its own (tests): T*N standard normals of (seed, run, side) as float64 on the host. */
 int xmca_surrogate(xmca_handle* h, int64_t n, uint64_t seed, uint32_t run, uint32_t side, double* out);
 
-/* hipEvent stage timers of the calls since the last reset: names are written as a ';'-separated list. */
+/* hipEvent stage timers of the calls since the last reset: names are written as a ';'-separated list.  Two
+ * kernel-level entries follow the stages when the eigensolver ran: "jacobi_round_kernel_ms" (total duration of the
+ * jacobi_fused_round_kernel launches, events around the rounds of every sweep) and "jacobi_round_kernel_launches"
+ * (their number, in the ms array). */
 int xmca_get_timings(xmca_handle* h, char* names, int names_len, double* ms, int max_n);
 int xmca_reset_timings(xmca_handle* h);
 

@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Golden vectors at the BASELINE.json configurations, from the REAL reference (build container only).
+
+Run:  PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg python oracle/make_config_goldens.py
+
+Cases (inputs are regenerated from seeds by tests/golden_inputs.py - SURVEY.md Appendix C generators):
+  c2_full     configs[1] at FULL size: EOF T = 2920 x N = 10 000 float64, solve() + rotate(10, 1)
+  c3_reduced  configs[2] at T = 1000 x (4000, 3000): MCA, complexify=True, rotate(20, 4) (geometric amplitudes)
+  c5_scaled   configs[4] at T = 1200 x 41 472 float32 (3-D input): EOF, solve() + rotate(10, 1)
+For each case the real `xmca.array.MCA` is run, `oracle/ref_numpy.py` is pinned against it (sigma, R, Phi, variance,
+Varimax iteration count) and the outputs are written to tests/golden/config_cases.npz: all singular values, the
+leading unrotated vectors (float32 / complex64 storage: 6e-8 relative, far below the 1e-5 they are compared at), R,
+Phi, norms, variance, mode order, explained variance, rotated PCs, iteration count.
+
+Also: bootstrapping goldens (reference `MCA.bootstrapping(3, ...)` under `np.random.seed(5)`) for the five
+parameterisations of tests/test_gpu_mca.py -> tests/golden/bootstrap_cases.npz.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+from make_goldens import OUT, SvdCounter, import_reference, rel  # noqa: E402
+from golden_inputs import make_input  # noqa: E402
+
+CONFIGS = [  # name, complexify, n_rot, power, modes of V stored, row stride of stored vectors
+    ("c2_full", False, 10, 1, 10, 1),
+    ("c3_reduced", True, 20, 4, 20, 1),
+    ("c5_scaled", False, 10, 1, 10, 2),
+]
+
+BOOT = [  # tag, input, single field, complexify, rotation, kwargs  (tests/test_gpu_mca.py bootstrapping cases)
+    ("small_std", "small_both", False, False, None, dict(on_left=True, on_right=True, block_size=2)),
+    ("wide_rot", "wide_both", False, False, (5, 2), dict(on_left=True, on_right=False, block_size=1)),
+    ("wide_single_cplx", "wide_both", True, True, None, dict(on_left=True, on_right=False, block_size=4, replace=False)),
+    ("wide_cplx_rot", "wide_both", False, True, (4, 1), dict(on_left=False, on_right=True, block_size=1)),
+    ("sst_iterative", "sst_prcp", False, False, None, dict(on_left=True, on_right=True, block_size=3, strategy='iterative')),
+]
+
+
+def config_case(MCA, name, cplx, n_rot, power, n_vec, stride):
+    from oracle import ref_numpy as O
+    fields = make_input(name)
+    t0 = time.perf_counter()
+    m = MCA(*fields)
+    t1 = time.perf_counter()
+    m.solve(complexify=cplx)
+    t2 = time.perf_counter()
+    keys = list(m._V.keys())
+    out = {
+        "singular_values": np.asarray(m._singular_values, dtype=np.float64),
+        "total_covariance": np.asarray(m._analysis["total_covariance"], dtype=np.float64),
+        "rank": np.asarray(m._analysis["rank"]),
+        "stride": np.asarray(stride),
+    }
+    store = np.complex64 if cplx else np.float32
+    for k in keys:
+        out["V_" + k] = np.ascontiguousarray(m._V[k][::stride, :n_vec]).astype(store)
+    with SvdCounter() as cnt:
+        m.rotate(n_rot, power)
+    t3 = time.perf_counter()
+    out.update({"n_iter": np.asarray(cnt.n), "R": m._rotation_matrix, "Phi": m._correlation_matrix,
+                "variance": np.asarray(m._variance, dtype=np.float64), "var_idx": m._var_idx,
+                "explained_variance": np.asarray(m.explained_variance(), dtype=np.float64)})
+    pcs = m.pcs(n_rot)
+    for k in keys:
+        out["norm_" + k] = np.asarray(m._norm[k], dtype=np.float64)
+        out["pcs_" + k] = pcs[k].astype(store)
+    out["cpu_seconds"] = np.asarray([t1 - t0, t2 - t1, t3 - t2])
+    print("%-11s reference: ctor %.1f s, solve %.1f s, rotate %.2f s, %d Varimax iterations" %
+          (name, t1 - t0, t2 - t1, t3 - t2, cnt.n), flush=True)
+
+    # pin the oracle at this size
+    om = O.OracleModel(*fields)
+    om.solve(complexify=cplx)
+    oo = om.rotate(n_rot, power)
+    f32 = np.asarray(fields[0]).dtype == np.float32
+    tol = 1e-5 if f32 else 1e-10
+    assert rel(om.singular_values, m._singular_values) < tol, name
+    assert oo["n_iter"] == cnt.n, (name, oo["n_iter"], cnt.n)
+    assert rel(oo["R"], m._rotation_matrix) < (1e-4 if f32 else 1e-9), name
+    assert rel(oo["variance"], m._variance) < (1e-4 if f32 else 1e-9), name
+    return out
+
+
+def bootstrap_case(MCA, inp, single, cplx, rot, kw):
+    fields = make_input(inp)
+    if single:
+        fields = fields[:1]
+    m = MCA(*fields)
+    m.solve(complexify=cplx)
+    if rot:
+        m.rotate(*rot)
+    np.random.seed(5)
+    return m.bootstrapping(3, n_modes=4, **kw)
+
+
+def main():
+    MCA, _, _ = import_reference()
+    only = sys.argv[1:]
+    if not only or "configs" in only:
+        out = {}
+        for name, cplx, n_rot, power, n_vec, stride in CONFIGS:
+            for k, v in config_case(MCA, name, cplx, n_rot, power, n_vec, stride).items():
+                out[name + "__" + k] = v
+        dst = os.path.join(OUT, "config_cases.npz")
+        np.savez_compressed(dst, **out)
+        print("wrote %s (%.2f MB)" % (dst, os.path.getsize(dst) / 1e6))
+    if not only or "bootstrap" in only:
+        out = {}
+        for tag, inp, single, cplx, rot, kw in BOOT:
+            out[tag] = bootstrap_case(MCA, inp, single, cplx, rot, kw)
+            print("bootstrap", tag, out[tag].shape)
+        dst = os.path.join(OUT, "bootstrap_cases.npz")
+        np.savez_compressed(dst, **out)
+        print("wrote %s (%.3f MB)" % (dst, os.path.getsize(dst) / 1e6))
+
+
+if __name__ == "__main__":
+    main()

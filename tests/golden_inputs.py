@@ -84,8 +84,55 @@ def _loadings(tag):
     return L @ Q
 
 
+def gen_A(T=2920, N=10_000, k=20, seed=0):
+    """SURVEY.md Appendix C generator A (BASELINE config C2): low-rank Gaussian signal + unit noise, float64."""
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal((T, k)) * np.linspace(10, 1, k)) @ rng.standard_normal((k, N)) \
+        + rng.standard_normal((T, N))
+
+
+def gen_B(T=5000, Nx=20_000, Ny=15_000, k=40, seed=3, geometric=False):
+    """SURVEY.md Appendix C generator B (configs C3 / C4): Hann patterns mixed by a random k x k matrix, cosine PCs,
+    float64.  `geometric=True`: amplitudes 10 * 0.85^j (leading gaps >= 10 %, for the 1e-5 loadings check)."""
+    rng = np.random.default_rng(seed)
+
+    def pat(N):
+        P = np.zeros((k, N))
+        w = N // k
+        for j in range(k):
+            P[j, j * w:(j + 1) * w] = np.hanning(w)
+        return rng.standard_normal((k, k)) @ P * 0.3 + P
+    t = np.arange(T)[:, None]
+    f = np.linspace(0.01, 0.2, k)[None, :]
+    amp = 10.0 * 0.85 ** np.arange(k) if geometric else np.linspace(10, 5, k)
+    pcs = amp * np.cos(2 * np.pi * f * t + rng.uniform(0, 6.28, (1, k)))
+    A = pcs @ pat(Nx) + 0.5 * rng.standard_normal((T, Nx))
+    B = pcs @ pat(Ny) + 0.5 * rng.standard_normal((T, Ny))
+    return A, B
+
+
+def gen_C(T=1200, ny=720, nx=1440, k=30, seed=5):
+    """SURVEY.md Appendix C generator C (config C5): float32 noise + k unmixed Hann patterns, 3-D input (T, ny, nx)."""
+    rng = np.random.default_rng(seed)
+    N = ny * nx
+    X = rng.standard_normal((T, N), dtype=np.float32) * np.float32(0.5)
+    P = np.zeros((k, N), dtype=np.float32)
+    w = N // k
+    for j in range(k):
+        P[j, j * w:(j + 1) * w] = np.hanning(w)
+    pcs = (rng.standard_normal((T, k)) * np.linspace(10, 5, k)).astype(np.float32)
+    X += pcs @ P
+    return X.reshape(T, ny, nx)
+
+
 def make_input(name):
     """Returns a tuple of 1 or 2 arrays (time first)."""
+    if name == "c2_full":            # BASELINE configs[1] at full size
+        return (gen_A(),)
+    if name == "c3_reduced":         # BASELINE configs[2] at T = 1000 x (4000, 3000), geometric amplitudes
+        return gen_B(1000, 4000, 3000, geometric=True)
+    if name == "c5_scaled":          # BASELINE configs[4] at T = 1200 x (144 x 288 = 41 472), float32, 3-D
+        return (gen_C(1200, 144, 288),)
     if name == "unit_left":
         return (_unit_fields()[0],)
     if name == "unit_both":

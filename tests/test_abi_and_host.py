@@ -32,7 +32,21 @@ def test_header_symbols_are_exported_and_bound():
 def test_library_is_built_for_gfx950_only():
     from xmca_amd import _hip
     blob = open(_hip.library_path(), "rb").read()
-    assert b"gfx950" in blob and b"sm_" not in blob[:0]       # offload bundle names its target
+    targets = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-f]+)", blob))       # code objects of the offload bundle
+    assert targets == {b"gfx950"}, targets
+    assert not re.search(rb"nvptx|sm_[0-9]{2}\b", blob)                           # no CUDA device code rides along
+
+
+def test_stale_library_is_refused(monkeypatch):
+    """a library built from another revision of include/xmca_hip.h (ABI number) is not bound silently"""
+    from xmca_amd import _hip
+    _hip.load_library()
+    header = open(os.path.join(REPO, "include", "xmca_hip.h")).read()
+    assert int(re.search(r"#define XMCA_ABI_VERSION (\d+)", header).group(1)) == _hip.ABI_VERSION
+    monkeypatch.setattr(_hip, "_lib", None)
+    monkeypatch.setattr(_hip, "ABI_VERSION", _hip.ABI_VERSION + 1)
+    with pytest.raises(ImportError, match="ABI"):
+        _hip.load_library()
 
 
 def test_no_gpu_means_loud_failure():

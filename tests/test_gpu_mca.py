@@ -516,3 +516,90 @@ def test_singular_vectors_are_fetched_lazily_and_survive_other_models():
     assert np.array_equal(a._V["right"], r._V["right"])    # the solver is deterministic
     a.solve(complexify=True)                                # re-solving drops the pending fetch instead of doing it
     assert np.iscomplexobj(a._V.head("left", 2))
+
+
+# ----------------------------------------------------------------------------------------------
+# regression tests of the round-1 review
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cplx,power", [(False, 1), (True, 3)])
+def test_varimax_hand_over_from_the_persistent_kernel(monkeypatch, cplx, power):
+    """When the single-launch Varimax loop cannot finish (a workgroup of its grid never becomes resident: partitioned
+    device, CUs held by another process) the per-iteration launches continue from the state it left.  Simulated by
+    stopping the persistent launch after 7 iterations: same R, same stop iteration as the uninterrupted loop."""
+    fields = make_input("unit_both")
+    m = MCA(*fields)
+    m.solve(complexify=cplx)
+    m.rotate(8, power)
+    n_iter, R, var = m._varimax_iterations, m._rotation_matrix.copy(), m._variance.copy()
+    assert n_iter > 20
+    monkeypatch.setenv("XMCA_VARIMAX_TEST_GIVEUP", "7")
+    m.rotate(8, power)
+    assert m._varimax_iterations == n_iter
+    assert _rel(m._rotation_matrix, R) < 1e-9 and _rel(m._variance, var) < 1e-9
+
+
+def test_unconverged_eigensolver_raises_like_gesdd(monkeypatch):
+    """the Jacobi sweeps either reach their stopping rule or the solve raises LinAlgError (numpy's 'SVD did not
+    converge'): an unconverged basis is never returned as singular vectors."""
+    m = MCA(*make_input("wide_both"))
+    monkeypatch.setenv("XMCA_JACOBI_MAX_SWEEPS", "2")
+    with pytest.raises(np.linalg.LinAlgError):
+        m.solve()
+    monkeypatch.delenv("XMCA_JACOBI_MAX_SWEEPS")
+    m.solve()
+    assert m._analysis['rank'] == 64
+
+
+def test_device_preprocessed_model_rescaled_after_a_complex_solve():
+    """preprocess='device', solve(complexify=True) on narrow fields (N <= T: the general path leaves an imaginary plane
+    on the device), then normalize() / apply_weights(): the reference simply rescales the fields and solves again."""
+    from xmca_amd import _hip
+    rng = np.random.default_rng(4)
+    left, right = rng.standard_normal((60, 20)) * np.linspace(1, 3, 20), rng.standard_normal((60, 14)) * np.linspace(2, 1, 14)
+    dev = MCA(left, right, handle=_hip.Handle(0), preprocess='device')
+    ref = MCA(left, right, preprocess='host')
+    for m in (dev, ref):
+        m.solve(complexify=True)
+        m.normalize()
+        m.apply_weights(left=np.linspace(0.5, 1.5, 20))
+        m.solve(complexify=True)
+    assert dev._store_is_raw                                       # still never came back to the host
+    assert _rel(dev._singular_values[:10], ref._singular_values[:10]) < 1e-10
+    om = O.OracleModel(left, right)
+    om.fields = [om.fields[0] / om.fields[0].std(axis=0) * np.linspace(0.5, 1.5, 20), om.fields[1] / om.fields[1].std(axis=0)]
+    om.solve(complexify=True)
+    assert _rel(dev._singular_values[:10], om.singular_values[:10]) < TOL
+
+
+def test_resident_fields_follow_host_side_rescaling():
+    """solve(), then normalize() on the host path: pcs() must project the UPDATED fields like the reference
+    (`_get_U` reads `_fields`), not the copy the device still holds from the solve."""
+    left, right = make_input("wide_both")
+    m = MCA(left, right, preprocess='host')
+    m.solve()
+    before = m.pcs(3)
+    m.normalize()
+    after = m.pcs(3)
+    X = m._get_X()
+    for k in m._keys:
+        ref = X[k] @ m._V[k][:, :3] / np.sqrt(m._singular_values[:3])
+        assert _rel(after[k], ref) < 1e-9
+        assert _rel(after[k], before[k]) > 1e-3                    # it did change
+
+
+def test_model_identity_is_not_its_address():
+    """a new model that happens to get the address of a collected one must not take over that one's resident fields"""
+    import gc
+    fields = make_input("wide_both")
+    a = MCA(*fields)
+    a.solve()
+    dev = a._device()
+    key = dev.fields_owner
+    assert a._owns_device_fields(dev)
+    del a
+    gc.collect()
+    for _ in range(50):
+        b = MCA(*make_input("small_both"))
+        assert not b._owns_device_fields(dev)
+        assert dev.fields_owner is key
+        del b

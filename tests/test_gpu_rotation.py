@@ -101,3 +101,16 @@ def test_varimax_many_modes_matches_oracle(hip, n, p, cplx, seed):
     assert out["n_iter"] == n_iter
     assert _rel(out["R"], R_ref) < TOL
     assert _rel(out["B"], B_ref) < TOL
+
+
+@pytest.mark.parametrize("tag,gamma", [("r10", 0.0), ("r10", 0.5), ("c4", 0.0), ("c10p4", 2.0), ("r4", 1.0)])
+def test_varimax_gamma_family_matches_oracle(hip, tag, gamma):
+    """`varimax(A, gamma)` (rotation.py:15, :56-57): gamma = 1 Varimax, 0 Quartimax, anything in between - same
+    trajectory, same stop iteration as the numpy restatement."""
+    from oracle import ref_numpy as O
+    from xmca_amd.tools.rotation import varimax
+    A = make_input("loadings_" + tag)[0]
+    Bo, Ro, n_iter = O.varimax(A, gamma=gamma)
+    B, R = varimax(A, gamma=gamma, handle=hip)
+    assert hip.last_iters == n_iter
+    assert _rel(R, Ro) < TOL and _rel(B, Bo) < TOL

@@ -1,0 +1,197 @@
+"""rule_n (xmca/array.py:1716-1771) on the GPU:
+
+* EXACT per-run parity: the device generator's normals of run r (`xmca_surrogate(seed, r, side)`) are fed to the numpy
+  oracle (MCA() -> solve -> rotate -> variance, oracle/ref_numpy.py) and compared with row r of `xmca_rule_n` - unrotated,
+  rotated real, complex, and a configuration where the reference drops runs (Varimax does not converge in 1000
+  iterations, array.py:1759-1763);
+* distribution: median and 1 % / 99 % quantiles of every leading mode over 400 device runs against 400 oracle runs fed
+  numpy normals, plus a two-sample Kolmogorov-Smirnov test;
+* two ranks on ONE device (gloo gather) give bit-for-bit the spectra of a single rank.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from golden_inputs import make_input
+from oracle import ref_numpy as O
+from xmca_amd.array import MCA
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _oracle_run(hip, T, widths, seed, run, cplx, rot):
+    data = [hip.surrogate(T * w, seed, run, side).reshape(T, w) for side, w in enumerate(widths)]
+    om = O.OracleModel(*data)
+    om.solve(complexify=cplx)
+    if rot:
+        om.rotate(*rot)                   # RuntimeError when Varimax does not converge: the reference drops the run
+    return om.variance()
+
+
+@pytest.mark.parametrize("T,widths,cplx,rot", [
+    (40, (24, 18), False, None),            # both fields narrower than T (primal route)
+    (60, (300, 200), False, None),          # both wider (values-only Cholesky route)
+    (60, (300, 200), True, None),           # analytic-signal subspace
+    (60, (300,), False, None),              # EOF
+    (48, (120, 30), True, None),            # mixed widths, complex
+    (60, (300, 200), False, (6, 1)),        # rotated: Varimax
+    (60, (300, 200), False, (5, 3)),        # rotated: Promax
+    (60, (200, 150), True, (4, 2)),         # rotated complex
+    (40, (24,), False, (4, 1)),             # rotated EOF
+])
+def test_rule_n_runs_equal_the_oracle_on_the_same_normals(hip, T, widths, cplx, rot):
+    seed, n_runs = 20240607, 5
+    n_fields = len(widths)
+    rank = min((T,) + widths)
+    p, power = rot if rot else (0, 0)
+    n_out = p if rot else rank
+    spectra, kept = hip.rule_n(T, widths[0], widths[1] if n_fields == 2 else 0, n_fields, cplx, bool(rot), p, max(power, 1), 1e-8,
+                               0, n_runs, seed, np.float64, n_out)
+    assert spectra.shape == (n_runs, n_out)
+    for r in range(n_runs):
+        try:
+            ref = _oracle_run(hip, T, widths, seed, r, cplx, rot)
+        except RuntimeError:
+            assert kept[r] == 0
+            continue
+        assert kept[r] == 1
+        assert ref.shape == (n_out,)
+        keep = ref > 1e-7 * ref[0]          # null modes (centering; the analytic signal keeps T/2 of them) carry rounding only
+        assert np.max(np.abs(spectra[r][keep] - ref[keep]) / ref[keep]) < 1e-5, (r, widths, cplx, rot)
+        assert np.all(np.abs(spectra[r][~keep]) < 1e-5 * ref[0])
+    # a later block of runs is keyed by the run index only
+    again, _ = hip.rule_n(T, widths[0], widths[1] if n_fields == 2 else 0, n_fields, cplx, bool(rot), p, max(power, 1), 1e-8,
+                          3, 5, seed, np.float64, n_out)
+    assert np.array_equal(again, spectra[3:5])
+
+
+def test_rule_n_drops_the_runs_the_reference_drops(hip):
+    """complex white noise, n_rot = 20, power = 4: Varimax needs more than 1000 iterations for most surrogates (SURVEY.md
+    6: 4/4 seeds at T = 1000) - the reference catches the RuntimeError and drops the run (array.py:1762-1763)."""
+    T, widths, seed, n_runs, rot = 100, (260, 200), 99, 6, (20, 4)
+    spectra, kept = hip.rule_n(T, widths[0], widths[1], 2, True, True, rot[0], rot[1], 1e-8, 0, n_runs, seed, np.float64, rot[0])
+    ref_kept = []
+    for r in range(n_runs):
+        try:
+            ref = _oracle_run(hip, T, widths, seed, r, True, rot)
+            ref_kept.append(1)
+            assert np.max(np.abs(spectra[r] - ref) / ref) < 1e-4          # (hundreds of iterations on noise: 1e-5 per iteration adds up)
+        except RuntimeError:
+            ref_kept.append(0)
+    assert list(kept) == ref_kept
+    assert 0 in ref_kept                                                  # the case is only useful if something is dropped
+    # ... and through the class: the dropped runs shrink the run axis
+    rng = np.random.default_rng(0)
+    m = MCA(rng.standard_normal((T, widths[0])), rng.standard_normal((T, widths[1])))
+    m.solve(complexify=True)
+    try:
+        m.rotate(*rot)
+    except RuntimeError:
+        pytest.skip("the model itself does not converge")
+    out = m.rule_n(n_runs, seed=seed)
+    assert out.shape == (rot[0], int(np.sum(ref_kept)))
+
+
+@pytest.mark.parametrize("cplx,rot", [(False, None), (True, None), (False, (4, 1))])
+def test_rule_n_distribution_quantiles_match_oracle(cplx, rot):
+    """per-mode median and 1 % / 99 % quantiles over >= 200 runs within Monte-Carlo error of the oracle's
+    (fed numpy normals), here 400 + 400 runs; the quantile errors use the normal approximation of the order statistics:
+    se(q_p) = sigma sqrt(p (1 - p) / n) / phi(z_p)."""
+    from scipy import stats
+    fields = make_input("small_both")
+    m = MCA(*fields)
+    m.solve(complexify=cplx)
+    om = O.OracleModel(*fields)
+    om.solve(complexify=cplx)
+    if rot:
+        m.rotate(*rot)
+        om.rotate(*rot)
+    n = 400
+    mine = m.rule_n(n, seed=7)
+    rng = np.random.default_rng(11)
+    ref = O.rule_n(om, n, normal=lambda shape: rng.standard_normal(shape))
+    assert mine.shape[0] == ref.shape[0] and mine.shape[1] >= 0.9 * n and ref.shape[1] >= 0.9 * n
+    k = min(6, ref.shape[0])
+    for mode in range(k):
+        a, b = mine[mode], ref[mode]
+        sd = np.sqrt(0.5 * (a.var() + b.var()))
+        for prob in (0.5, 0.01, 0.99):
+            z = stats.norm.ppf(prob)
+            se = sd * np.sqrt(prob * (1 - prob)) / stats.norm.pdf(z) * np.sqrt(1.0 / len(a) + 1.0 / len(b))
+            assert abs(np.quantile(a, prob) - np.quantile(b, prob)) < 5 * se, (mode, prob)
+        assert stats.ks_2samp(a, b).pvalue > 1e-4, mode
+
+
+# ----------------------------------------------------------------------------------------------
+# two ranks, one device: sharded rule_n + gather (gloo here; the same code path uses RCCL under backend "nccl")
+# ----------------------------------------------------------------------------------------------
+def _worker(rank, world, port, n_runs, q):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import torch.distributed as td
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    from golden_inputs import make_input as mk
+    from xmca_amd import _hip
+    from xmca_amd.array import MCA as M
+    m = M(*mk("wide_both"), handle=_hip.Handle(0))
+    m.solve(complexify=True)
+    out = m.rule_n(n_runs, seed=1000 + rank)        # ranks disagree on purpose: rank 0's seed is broadcast
+    m.rotate(5, 2)
+    out_rot = m.rule_n(n_runs, seed=77)
+    q.put((rank, out, out_rot))
+    td.destroy_process_group()
+
+
+def test_two_ranks_on_one_device_equal_a_single_rank():
+    import torch.multiprocessing as mp
+    from xmca_amd import _hip
+    n_runs, world = 7, 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_runs, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    m = MCA(*make_input("wide_both"), handle=_hip.Handle(0))
+    m.solve(complexify=True)
+    single = m.rule_n(n_runs, seed=1000)
+    m.rotate(5, 2)
+    single_rot = m.rule_n(n_runs, seed=77)
+    for _, out, out_rot in results:
+        assert np.array_equal(out, single)                   # bit for bit: the generator is keyed by (seed, run, side)
+        assert np.array_equal(out_rot, single_rot)
+
+
+def test_bench_py_launches_its_own_ranks():
+    """`python bench.py --gpus 2` outside a launcher starts two ranks itself (here both on GPU 0, gloo gather) and reports
+    n_gpus = 2 with the run-sharded rule_n - the flow the driver's 2/4/8-GPU scaling runs use (RCCL there)."""
+    import json
+    import subprocess
+    env = dict(os.environ, XMCA_BENCH_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--T", "400",
+                        "--N", "1500", "--no-cpu-baseline", "--no-e2e", "--rule-n-runs", "1"], env=env, cwd=REPO,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                  # rank 0 only
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rule_n"]["runs"] == 2 and line["rule_n"]["shape"] == [5000, 2]
+    assert line["rule_n"]["spectrum_sum_check"] < 1e-9 and line["roofline"]["kernel"].startswith("jacobi_fused_round_kernel")
+    # a launcher that started a different number of ranks than --gpus is an error, not a silent n_gpus = 1
+    bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4", "--steps", "1"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=REPO, capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr

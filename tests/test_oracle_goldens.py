@@ -109,3 +109,26 @@ def test_rule_n_goldens(tag, name, cplx, rot):
     np.random.seed(1234)
     mine = O.rule_n(om, 3)
     assert mine.shape == g[tag].shape and _rel(mine, g[tag]) < 1e-10
+
+
+@pytest.mark.parametrize("name,cplx,n_rot,power", [("c2_full", False, 10, 1), ("c3_reduced", True, 20, 4), ("c5_scaled", False, 10, 1)])
+def test_config_goldens(name, cplx, n_rot, power):
+    """the BASELINE.json configurations (C2 at full size, C3 / C5 scaled) from the real reference
+    (oracle/make_config_goldens.py): sigma, leading loadings, R, variance and the Varimax iteration count."""
+    g = _load("config_cases.npz")
+    g = {k[len(name) + 2:]: g[k] for k in g.files if k.startswith(name + "__")}
+    fields = make_input(name)
+    f32 = fields[0].dtype == np.float32
+    om = O.OracleModel(*fields)
+    om.solve(complexify=cplx)
+    assert om.rank == int(g["rank"])
+    assert _rel(om.singular_values, g["singular_values"]) < (1e-5 if f32 else 1e-10)
+    stride = int(g["stride"])
+    for i, k in enumerate(["left", "right"][:len(om.V)]):
+        gv = g["V_" + k]
+        mine, _ = align_modes(om.V[i][::stride, :gv.shape[1]], gv)
+        assert _rel(mine, gv) < (1e-3 if f32 else 1e-6)           # (stored as float32 / complex64)
+    out = om.rotate(n_rot, power)
+    assert out["n_iter"] == int(g["n_iter"])
+    assert _rel(out["variance"], g["variance"]) < (1e-4 if f32 else 1e-9)
+    assert np.array_equal(out["var_idx"], g["var_idx"])

@@ -6,5 +6,5 @@
 The numerical core lives in libxmca_hip.so (HIP kernels + C ABI, see include/xmca_hip.h); build it with
 `python -m xmca_amd.build`.
 """
-__version__ = '0.1.0'
+__version__ = '0.2.0'
 __all__ = ['__version__']

@@ -27,6 +27,7 @@ _ip = ctypes.POINTER(ctypes.c_int)
 # name -> (restype, argtypes); the ABI test checks every one of these is exported
 SIGNATURES = {
     "xmca_version": (ctypes.c_char_p, []),
+    "xmca_abi_version": (_c_int, []),
     "xmca_device_count": (_c_int, []),
     "xmca_create": (_c_int, [_c_int, ctypes.POINTER(_vp)]),
     "xmca_destroy": (None, [_vp]),
@@ -46,7 +47,7 @@ SIGNATURES = {
     "xmca_project": (_c_int, [_vp, _c_int, _vp, _c_i64, _c_i64, _c_int, _vp, ctypes.POINTER(_c_int)]),
     "xmca_is_complex": (_c_int, [_vp]),
     "xmca_get_solve_info": (_c_int, [_vp, _vp, _c_int]),
-    "xmca_rotate_loadings": (_c_int, [_vp, _vp, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_dbl, _c_int, _c_int,
+    "xmca_rotate_loadings": (_c_int, [_vp, _vp, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_dbl, _c_int, _c_int, _c_dbl,
                                       _vp, _vp, _vp, _vp, _vp, _ip]),
     "xmca_rule_n": (_c_int, [_vp, _c_i64, _c_i64, _c_i64, _c_int, _vp, _c_int, _c_int, _c_int, _c_dbl, _c_i64, _c_i64,
                              ctypes.c_uint64, _c_int, _vp, _vp, _c_i64]),
@@ -68,8 +69,13 @@ def library_path():
     return _build.LIB
 
 
+ABI_VERSION = 3          # bumped whenever a signature of include/xmca_hip.h changes; checked against xmca_abi_version()
+
+
 def load_library():
-    """Loads (building first if the sources are newer and hipcc is present)."""
+    """Loads libxmca_hip.so and binds every symbol of include/xmca_hip.h.  The library is never built implicitly
+    (`python -m xmca_amd.build` / `__graft_entry__.build()` do that); a missing library, a missing symbol or a library
+    built from an older header (ABI number) raises ImportError - there is no CPU fallback."""
     global _lib
     if _lib is not None:
         return _lib
@@ -80,9 +86,17 @@ def load_library():
             "--offload-arch=gfx950). There is no CPU fallback." % path)
     lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as err:
+            raise ImportError("xmca_amd: %s does not export %s - rebuild it with `python -m xmca_amd.build --force`"
+                              % (path, name)) from err
         fn.restype = res
         fn.argtypes = args
+    have = lib.xmca_abi_version()
+    if have != ABI_VERSION:
+        raise ImportError("xmca_amd: %s was built for ABI %d, this package binds ABI %d - rebuild it with "
+                          "`python -m xmca_amd.build --force`" % (path, have, ABI_VERSION))
     _lib = lib
     return lib
 
@@ -205,6 +219,7 @@ class Handle:
     def set_field_device(self, side, re_ptr, im_ptr, T, N, dtype):
         """Adopt device pointers (e.g. torch tensors' data_ptr()); the caller keeps them alive."""
         self.release_result()
+        self.fields_owner = None
         self._check(self._lib.xmca_set_field(self._h, side, _vp(re_ptr), _vp(im_ptr) if im_ptr else None, T, N,
                                              _np_dtype_code(dtype), DEVICE))
 
@@ -318,7 +333,7 @@ class Handle:
         return r
 
     # ---- rotation -----------------------------------------------------------------------------
-    def rotate_loadings(self, L, n_left, power=1, tol=1e-8, max_iter=1000, varimax_only=False, want_B=False):
+    def rotate_loadings(self, L, n_left, power=1, tol=1e-8, max_iter=1000, varimax_only=False, want_B=False, gamma=1.0):
         L = np.asarray(L)
         cplx = np.iscomplexobj(L)
         Ld = np.ascontiguousarray(L, dtype=np.complex128 if cplx else np.float64)
@@ -331,7 +346,7 @@ class Handle:
         B = np.empty((N, p), dtype=cdt) if want_B else None
         iters = _c_int(0)
         rc = self._lib.xmca_rotate_loadings(self._h, _ptr(Ld), N, int(n_left), p, int(cplx), int(power), float(tol),
-                                            int(max_iter), int(varimax_only), _ptr(B), _ptr(R), _ptr(Phi), _ptr(nl),
+                                            int(max_iter), int(varimax_only), float(gamma), _ptr(B), _ptr(R), _ptr(Phi), _ptr(nl),
                                             _ptr(nr), ctypes.byref(iters))
         self.last_iters = int(iters.value)
         self._check(rc)

@@ -126,6 +126,7 @@ class MCA:
         self._pending_hilbert = False
         self._device_hilbert = False
         self._upload_serial = 0
+        self._token = object()              # identity of this model as owner of a handle's resident fields (never reused, unlike id())
         self._shape = {}
         self._field_names = {}
         self._field_means = {}
@@ -182,9 +183,15 @@ class MCA:
         self._fields_store = value
         self._pending_hilbert = False
         self._store_is_raw = False
+        self._upload_serial = getattr(self, '_upload_serial', 0) + 1    # whatever the device still holds is stale now
+
+    def _owner_key(self):
+        if not hasattr(self, '_token'):          # models built without __init__ (bench / load flows)
+            self._token = object()
+        return (self._token, self._upload_serial)
 
     def _owns_device_fields(self, dev):
-        return getattr(dev, 'fields_owner', None) == (id(self), self._upload_serial)
+        return getattr(dev, 'fields_owner', None) == self._owner_key()
 
     def _ingest_on_device(self, data):
         """preprocess='device': upload the raw fields, drop their NaN columns and center them there, keep them resident.
@@ -214,7 +221,7 @@ class MCA:
             store[k] = _RawField(f, keep[k])
         self._fields_store = store              # stand-ins: only shape / dtype are read while `_store_is_raw`
         self._store_is_raw = True
-        dev.fields_owner = (id(self), self._upload_serial)
+        dev.fields_owner = self._owner_key()
         return True
 
     def _materialize_fields(self):
@@ -378,6 +385,9 @@ class MCA:
                 cols[k] = np.ascontiguousarray(np.broadcast_to(w.reshape(-1) if w.ndim else w, (f.shape[1],)), dtype=f.dtype)
             except ValueError:
                 return False
+        # a complexified solve on the general path leaves an imaginary plane next to the resident real one; the real
+        # plane is untouched and the next solve re-complexifies (the reference simply rescales `_fields`)
+        dev.decomplexify()
         for side, k in enumerate(self._keys):
             dev.scale_field(side, cols[k], divide)
             self._fields_store[k].ops.append((divide, cols[k]))
@@ -480,8 +490,8 @@ class MCA:
 
         try:
             rank = dev.solve(len(self._keys))
-        except np.linalg.LinAlgError:
-            raise np.linalg.LinAlgError('''SVD failed. NaN entries may be the problem.''')
+        except np.linalg.LinAlgError as err:                       # array.py:575-578 (the device message is the cause)
+            raise np.linalg.LinAlgError('''SVD failed. NaN entries may be the problem.''') from err
 
         real_dtype = _real_dtype(next(iter(self._fields_store.values())).dtype)
         singular_values = dev.singular_values(rank).astype(real_dtype, copy=False)
@@ -571,12 +581,12 @@ class MCA:
             dev.set_field(side, _device_ready(store[k]))
         if self._device_hilbert and not any(np.iscomplexobj(f) for f in store.values()):
             dev.complexify(self._n_observations['left'])        # (a materialised host analytic signal goes up as it is)
-        dev.fields_owner = (id(self), self._upload_serial)
+        dev.fields_owner = self._owner_key()
 
     def _project_on_device(self, V):
         """fields[k] @ V[k] of `_get_U` (array.py:391) as a device GEMM over the resident fields."""
         dev = self._device()
-        if getattr(dev, 'fields_owner', None) != (id(self), self._upload_serial):
+        if not self._owns_device_fields(dev):
             self._upload_serial += 1          # another model / rule_n used the handle in between: upload again
             self._upload_fields(dev)
         T = self._n_observations['left']
@@ -775,7 +785,7 @@ class MCA:
         import scipy.stats
         pcs = self._get_pcs(n=n, phase_shift=phase_shift)
         dev = self._device()
-        if getattr(dev, 'fields_owner', None) != (id(self), self._upload_serial):
+        if not self._owns_device_fields(dev):
             self._upload_serial += 1
             self._upload_fields(dev)
         n_obs = self._n_observations['left']

@@ -175,8 +175,8 @@ __device__ __forceinline__ void rot_accum_body(double* __restrict__ sm, const do
           }
         }
         if (MODE == 0) {
-          // W = (|z|^2 - c_k / N) z     (rotation.py:56-57)
-          const double f = zr * zr + zi * zi - cvec[k] / (double)N;
+          // W = (|z|^2 - gamma c_k / N) z     (rotation.py:56-57; MODE 0 carries gamma in the `power` argument)
+          const double f = zr * zr + zi * zi - power * (cvec[k] / (double)N);
           zr *= f;
           zi *= f;
         }
@@ -919,14 +919,14 @@ __global__ __launch_bounds__(256) void varimax_iter_kernel(const double* __restr
                                                            const double* __restrict__ h, int64_t N, int p,
                                                            const double* __restrict__ A0r, const double* __restrict__ A0i,
                                                            double* Rr, double* Ri, double* cvec, double* state, double* part_r,
-                                                           double* part_i, unsigned int* counter, double tol) {
+                                                           double* part_i, unsigned int* counter, double tol, double gamma) {
   if (state[1] != 0.0 || state[4] != 0.0) return;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* sm = reinterpret_cast<double*>(smem_raw);
 #ifdef XMCA_ROT_PROF
   const long long t_start = (long long)__builtin_readcyclecounter();
 #endif
-  rot_accum_body<CPLX, 0, 0>(sm, Ar, Ai, h, N, N, p, Rr, Ri, cvec, nullptr, 1.0, part_r, part_i, nullptr);
+  rot_accum_body<CPLX, 0, 0>(sm, Ar, Ai, h, N, N, p, Rr, Ri, cvec, nullptr, gamma, part_r, part_i, nullptr);
 #ifdef XMCA_ROT_PROF
   const long long t_acc = (long long)__builtin_readcyclecounter();
 #endif
@@ -966,7 +966,7 @@ __device__ __forceinline__ void varimax_accum_mfma(double* __restrict__ sm, cons
                                                    const double* __restrict__ Rr, const double* __restrict__ Ri,
                                                    const double* __restrict__ cvec, double* __restrict__ out_r,
                                                    double* __restrict__ out_i, double* __restrict__ res_r,
-                                                   double* __restrict__ res_i, const bool res_ready) {
+                                                   double* __restrict__ res_i, const bool res_ready, const double gamma) {
   const int pl = p * ROT_LDP, pp = p * p;
   double* Xr = sm;
   double* Yr = Xr + pl;
@@ -982,11 +982,11 @@ __device__ __forceinline__ void varimax_accum_mfma(double* __restrict__ sm, cons
     Rsr[e] = Rr[e];
     if constexpr (CPLX) Rsi[e] = Ri[e];
   }
-  double cn[MAXT];                        // c_k / N for this lane's column of mode tile kt
+  double cn[MAXT];                        // gamma c_k / N for this lane's column of mode tile kt
 #pragma unroll
   for (int kt = 0; kt < MAXT; ++kt) {
     const int k = kt * 16 + l15;
-    cn[kt] = (kt < PT && k < p) ? cvec[k] / (double)N : 0.0;
+    cn[kt] = (kt < PT && k < p) ? gamma * (cvec[k] / (double)N) : 0.0;
   }
   d4_t gr[MAXT], gi[MAXT];
 #pragma unroll
@@ -1140,7 +1140,7 @@ __global__ __launch_bounds__(256) void varimax_persistent_kernel(const double* _
                                                                  const double* __restrict__ A0r, const double* __restrict__ A0i,
                                                                  double* Rr, double* Ri, double* cvec, double* state, double* part_r,
                                                                  double* part_i, unsigned int* flags, double tol, int max_iter,
-                                                                 size_t work_doubles, int resident_tiles) {
+                                                                 size_t work_doubles, int resident_tiles, double gamma) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* sm = reinterpret_cast<double*>(smem_raw);          // accumulate / polar scratch (time-shared)
   const int pp = p * p, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1173,7 +1173,7 @@ __global__ __launch_bounds__(256) void varimax_persistent_kernel(const double* _
     double* pub_r = part_r + (size_t)(it & 1) * nwg * pp;
     double* pub_i = CPLX ? part_i + (size_t)(it & 1) * nwg * pp : nullptr;
     ROT_STAMP(0);
-    varimax_accum_mfma<CPLX>(sm, Ar, Ai, N, p, Rl_r, Rl_i, cl, acc_r, acc_i, res_r, res_i, it > 0);
+    varimax_accum_mfma<CPLX>(sm, Ar, Ai, N, p, Rl_r, Rl_i, cl, acc_r, acc_i, res_r, res_i, it > 0, gamma);
     __syncthreads();
     ROT_STAMP(1);
     for (int e = tid; e < pp; e += 256) {

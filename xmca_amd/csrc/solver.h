@@ -792,6 +792,7 @@ class Rotator {
  public:
   hipStream_t st;
   StageTimer& tm;
+  double gamma = 1.0;   // Varimax family parameter (rotation.py:15,56-57): 1 = Varimax (what MCA.rotate uses), 0 = Quartimax
   Rotator(hipStream_t s, StageTimer& t) : st(s), tm(t) {}
 
   static int pick_nwg(int64_t N) {
@@ -866,7 +867,18 @@ class Rotator {
     const int tiles_per_wg = (int)(((d.N + ROT_PB - 1) / ROT_PB + d.nwg - 1) / d.nwg);
     const bool resident = persist_smem + rot_resident_smem(p, CPLX, tiles_per_wg) <= 160 * 1024;
     if (resident) persist_smem += rot_resident_smem(p, CPLX, tiles_per_wg);
-    if (fused && persist_on && persist_smem <= 160 * 1024 && d.nwg <= 256 && max_iter > 0) {
+    // the epoch exchange spins on every workgroup of the grid: all of them must be co-resident, one per CU (a
+    // partitioned / CU-masked device has fewer CUs than the 128-workgroup cap -> per-iteration launches instead)
+    static const int n_cus = [] {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+      return n;
+    }();
+    if (fused && persist_on && persist_smem <= 160 * 1024 && d.nwg <= 256 && d.nwg <= n_cus && max_iter > 0) {
+      // XMCA_VARIMAX_TEST_GIVEUP=k (tests): the persistent launch stops after k iterations, as if a workgroup had gone
+      // missing there, and the per-iteration launches take over - the hand-over must not change R or the stop iteration
+      const char* tg = std::getenv("XMCA_VARIMAX_TEST_GIVEUP");
+      const int persist_iters = (tg && std::atoi(tg) > 0) ? std::min(std::atoi(tg), max_iter) : max_iter;
       d.pflags.ensure((size_t)d.nwg);
       d.ppart_r.ensure((size_t)2 * d.nwg * p * p);
       if (CPLX) d.ppart_i.ensure((size_t)2 * d.nwg * p * p);
@@ -875,13 +887,22 @@ class Rotator {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_smem));
       hipLaunchKernelGGL((varimax_persistent_kernel<CPLX>), dim3(d.nwg), dim3(256), persist_smem, st, d.A.r(), d.A.i(CPLX), d.h.get(),
                          d.N, p, d.A0.r(), d.A0.i(CPLX), d.R.r(), d.R.i(CPLX), d.cvec.get(), d.state.get(), d.ppart_r.get(),
-                         CPLX ? d.ppart_i.get() : nullptr, d.pflags.get(), tol, max_iter, work_bytes / sizeof(double),
-                         resident ? tiles_per_wg : 0);
+                         CPLX ? d.ppart_i.get() : nullptr, d.pflags.get(), tol, persist_iters, work_bytes / sizeof(double),
+                         resident ? tiles_per_wg : 0, gamma);
       XMCA_HIP(hipGetLastError());
       XMCA_HIP(hipMemcpyAsync(state, d.state.get(), sizeof(state), hipMemcpyDeviceToHost, st));
       XMCA_HIP(hipStreamSynchronize(st));
-      XMCA_CHECK(state[4] != 2.0, XMCA_ERR_HIP, "varimax: a workgroup of the persistent kernel never arrived (grid not resident?)");
-      launched = max_iter;
+      if (state[4] == 2.0 || (persist_iters < max_iter && state[1] == 0.0 && state[4] == 0.0)) {
+        // a workgroup never arrived (grid not resident: another process holds CUs).  Workgroup 0 has written the R, c
+        // and iteration state of the last completed iteration: clear the flag and let the per-iteration launches below
+        // finish the loop from there.
+        state[4] = 0.0;
+        XMCA_HIP(hipMemcpyAsync(d.state.get(), state, sizeof(state), hipMemcpyHostToDevice, st));
+        XMCA_HIP(hipStreamSynchronize(st));
+        launched = (int)state[0];
+      } else {
+        launched = max_iter;
+      }
     }
     while (launched < max_iter) {
       const int batch = std::min(32, max_iter - launched);
@@ -889,9 +910,9 @@ class Rotator {
         if (fused) {
           hipLaunchKernelGGL((varimax_iter_kernel<CPLX>), dim3(d.nwg), dim3(256), fused_smem, st, d.A.r(), d.A.i(CPLX), d.h.get(), d.N,
                              p, d.A0.r(), d.A0.i(CPLX), d.R.r(), d.R.i(CPLX), d.cvec.get(), d.state.get(), d.part_r.get(),
-                             CPLX ? d.part_i.get() : nullptr, d.counter.get(), tol);
+                             CPLX ? d.part_i.get() : nullptr, d.counter.get(), tol, gamma);
         } else {
-          accum<CPLX, 0, 0>(d, 1.0, nullptr, nullptr);
+          accum<CPLX, 0, 0>(d, gamma, nullptr, nullptr);      // (MODE 0 carries gamma in the `power` slot)
           hipLaunchKernelGGL((varimax_step_kernel<CPLX>), dim3(1), dim3(256), 0, st, d.part_r.get(), CPLX ? d.part_i.get() : nullptr,
                              d.nwg, p, d.A0.r(), d.A0.i(CPLX), d.R.r(), d.R.i(CPLX), d.W.r(), d.W.i(CPLX), d.cvec.get(), d.state.get(), tol, 0);
         }

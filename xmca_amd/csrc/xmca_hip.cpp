@@ -56,7 +56,8 @@ struct xmca_handle {
 
 extern "C" {
 
-const char* xmca_version(void) { return "xmca_amd 0.1.0 (gfx950)"; }
+const char* xmca_version(void) { return "xmca_amd 0.2.0 (gfx950)"; }
+int xmca_abi_version(void) { return XMCA_ABI_VERSION; }
 
 int xmca_device_count(void) {
   int n = 0;
@@ -759,7 +760,7 @@ int xmca_correlate(xmca_handle* h, int side, const double* Y, int64_t T, int64_t
 }
 
 int xmca_rotate_loadings(xmca_handle* h, const double* L, int64_t N, int64_t n_left, int p, int is_complex, int power,
-                         double tol, int max_iter, int varimax_only, double* B_out, double* R_out, double* Phi_out,
+                         double tol, int max_iter, int varimax_only, double gamma, double* B_out, double* R_out, double* Phi_out,
                          double* norm_left, double* norm_right, int* iters_out) {
   API_BEGIN(h)
   XMCA_CHECK(L && N >= 1 && p >= 2, XMCA_ERR_INVALID, "rotate: need N x p loadings with p >= 2");
@@ -767,6 +768,7 @@ int xmca_rotate_loadings(xmca_handle* h, const double* L, int64_t N, int64_t n_l
   XMCA_CHECK(n_left >= 0 && n_left <= N && max_iter >= 1, XMCA_ERR_INVALID, "rotate: bad n_left / max_iter");
   const bool cplx = is_complex != 0;
   Rotator rot(h->st, h->tm);
+  rot.gamma = gamma;
   RotationDevice& d = h->rot;
   rot.alloc(d, N, n_left, p, cplx);
   const size_t nl = (size_t)N * p * (cplx ? 2 : 1);
@@ -836,6 +838,15 @@ int xmca_get_timings(xmca_handle* h, char* names, int names_len, double* ms, int
     if (ms) ms[n] = h->tm.ms[name];
     ++n;
   }
+  // kernel-level entries: total duration and launch count of the eigensolver's fused round kernel (hipEvents around the
+  // rounds of every sweep, jacobi_impl.inc) - ms[] carries the count for the second name
+  const double rk_ms = h->ews.w64.round_ms + h->ews.w32.round_ms;
+  const double rk_n = (double)(h->ews.w64.round_launches + h->ews.w32.round_launches);
+  if (rk_n > 0 && n + 2 <= max_n) {
+    joined += (n ? ";" : "") + std::string("jacobi_round_kernel_ms;jacobi_round_kernel_launches");
+    if (ms) { ms[n] = rk_ms; ms[n + 1] = rk_n; }
+    n += 2;
+  }
   if (names && names_len > 0) {
     std::strncpy(names, joined.c_str(), (size_t)names_len - 1);
     names[names_len - 1] = 0;
@@ -846,6 +857,8 @@ int xmca_get_timings(xmca_handle* h, char* names, int names_len, double* ms, int
 int xmca_reset_timings(xmca_handle* h) {
   if (!h) return XMCA_ERR_INVALID;
   try { h->tm.reset(); } catch (...) { return XMCA_ERR_HIP; }
+  h->ews.w64.round_ms = h->ews.w32.round_ms = 0.0;
+  h->ews.w64.round_launches = h->ews.w32.round_launches = 0;
   return XMCA_OK;
 }
 

@@ -80,6 +80,7 @@ class xMCA(MCA):
                 msg = ('Error for {:} weights. Mismatch between dimensions of weights ({:}) and original field ({:}).')
                 raise ValueError(msg.format(k, weight.shape, fields[k].shape)) from err
             store[k] = new
+        self._fields = store              # (through the setter: the copy a device may still hold is stale now)
 
     def apply_coslat(self):
         """Weight by sqrt(cos(lat)) (area weighting on a regular grid)."""
