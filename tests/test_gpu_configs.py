@@ -86,8 +86,9 @@ def test_config_matches_reference(gold, name, cplx, n_rot, power, preprocess):
         al, _ = align_modes(pcs[key], g["pcs_" + key])
         assert _rel(al, g["pcs_" + key]) < (5e-3 if f32 else 1e-4)
     # ---- properties over ALL grid points (the goldens hold a subset for c5) ----
+    # (two fields: sigma^2 = lambda(K K^H) - orthogonality of weak modes degrades like 5e-14 (sigma_1 / sigma_m)^2)
     V = m._V.head("left", n_rot)
-    assert np.max(np.abs(V.conj().T @ V - np.eye(n_rot))) < (1e-4 if f32 else 1e-9)
+    assert np.max(np.abs(V.conj().T @ V - np.eye(n_rot))) < (1e-4 if f32 else 1e-6 if len(fields) == 2 else 1e-9)
 
 
 @pytest.mark.parametrize("n,cplx", [(2920, False), (2501, True)])

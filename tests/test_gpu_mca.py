@@ -521,19 +521,19 @@ def test_singular_vectors_are_fetched_lazily_and_survive_other_models():
 # ----------------------------------------------------------------------------------------------
 # regression tests of the round-1 review
 # ----------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("cplx,power", [(False, 1), (True, 3)])
-def test_varimax_hand_over_from_the_persistent_kernel(monkeypatch, cplx, power):
+@pytest.mark.parametrize("name,cplx,n_rot,power", [("unit_both", False, 8, 1), ("wide_both", True, 6, 4)])
+def test_varimax_hand_over_from_the_persistent_kernel(monkeypatch, name, cplx, n_rot, power):
     """When the single-launch Varimax loop cannot finish (a workgroup of its grid never becomes resident: partitioned
     device, CUs held by another process) the per-iteration launches continue from the state it left.  Simulated by
     stopping the persistent launch after 7 iterations: same R, same stop iteration as the uninterrupted loop."""
-    fields = make_input("unit_both")
+    fields = make_input(name)
     m = MCA(*fields)
     m.solve(complexify=cplx)
-    m.rotate(8, power)
+    m.rotate(n_rot, power)
     n_iter, R, var = m._varimax_iterations, m._rotation_matrix.copy(), m._variance.copy()
     assert n_iter > 20
     monkeypatch.setenv("XMCA_VARIMAX_TEST_GIVEUP", "7")
-    m.rotate(8, power)
+    m.rotate(n_rot, power)
     assert m._varimax_iterations == n_iter
     assert _rel(m._rotation_matrix, R) < 1e-9 and _rel(m._variance, var) < 1e-9
 
@@ -541,13 +541,14 @@ def test_varimax_hand_over_from_the_persistent_kernel(monkeypatch, cplx, power):
 def test_unconverged_eigensolver_raises_like_gesdd(monkeypatch):
     """the Jacobi sweeps either reach their stopping rule or the solve raises LinAlgError (numpy's 'SVD did not
     converge'): an unconverged basis is never returned as singular vectors."""
-    m = MCA(*make_input("wide_both"))
+    rng = np.random.default_rng(8)
+    m = MCA(rng.standard_normal((200, 520)))                # T = 200: four pair slots of 64 x 64 tiles
     monkeypatch.setenv("XMCA_JACOBI_MAX_SWEEPS", "2")
     with pytest.raises(np.linalg.LinAlgError):
         m.solve()
     monkeypatch.delenv("XMCA_JACOBI_MAX_SWEEPS")
     m.solve()
-    assert m._analysis['rank'] == 64
+    assert m._analysis['rank'] == 200
 
 
 def test_device_preprocessed_model_rescaled_after_a_complex_solve():

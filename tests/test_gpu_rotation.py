@@ -103,7 +103,7 @@ def test_varimax_many_modes_matches_oracle(hip, n, p, cplx, seed):
     assert _rel(out["B"], B_ref) < TOL
 
 
-@pytest.mark.parametrize("tag,gamma", [("r10", 0.0), ("r10", 0.5), ("c4", 0.0), ("c10p4", 2.0), ("r4", 1.0)])
+@pytest.mark.parametrize("tag,gamma", [("r10", 0.0), ("r10", 0.5), ("c4", 0.0), ("c10p4", 0.3), ("r4", 1.0)])
 def test_varimax_gamma_family_matches_oracle(hip, tag, gamma):
     """`varimax(A, gamma)` (rotation.py:15, :56-57): gamma = 1 Varimax, 0 Quartimax, anything in between - same
     trajectory, same stop iteration as the numpy restatement."""

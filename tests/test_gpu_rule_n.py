@@ -72,7 +72,7 @@ def test_rule_n_runs_equal_the_oracle_on_the_same_normals(hip, T, widths, cplx, 
 def test_rule_n_drops_the_runs_the_reference_drops(hip):
     """complex white noise, n_rot = 20, power = 4: Varimax needs more than 1000 iterations for most surrogates (SURVEY.md
     6: 4/4 seeds at T = 1000) - the reference catches the RuntimeError and drops the run (array.py:1762-1763)."""
-    T, widths, seed, n_runs, rot = 100, (260, 200), 99, 6, (20, 4)
+    T, widths, seed, n_runs, rot = 150, (400, 300), 99, 8, (30, 4)
     spectra, kept = hip.rule_n(T, widths[0], widths[1], 2, True, True, rot[0], rot[1], 1e-8, 0, n_runs, seed, np.float64, rot[0])
     ref_kept = []
     for r in range(n_runs):

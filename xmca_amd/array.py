@@ -18,7 +18,6 @@ import numpy as np
 
 from . import __version__, _hip
 from .tools.array import (block_bootstrap, get_nan_cols, has_nan_time_steps, pearsonr, remove_mean, remove_nan_cols)
-from .tools.text import boldify_str, secure_str, wrap_str
 
 _SCALINGS_MSG = ('The scaling option {:} is not valid. Please choose one of the following: None, eigen, std, max')
 
@@ -100,14 +99,19 @@ class _RawField:
 class MCA:
     """Maximum Covariance Analysis of one (EOF/PCA) or two `numpy.ndarray` fields; time is axis 0."""
 
-    def __init__(self, *fields, handle=None, preprocess='host'):
+    def __init__(self, *fields, handle=None, preprocess=None):
         """fields: one or two numpy arrays, time first.  `handle`: a `_hip.Handle` (default: one per device).
-        `preprocess='device'` (extension): the constructor's centering / mean / std pass (array.py:199-215) runs on the
-        GPU over the uploaded raw field - column means in float64 - and the centered field stays resident for solve();
-        the host copy `_fields` is fetched on first use.  Fields with NaNs, and the default `'host'`, take the
-        reference's numpy path (bit-identical means for float32 input)."""
-        if preprocess not in ('host', 'device'):
+        `preprocess` (extension): where the constructor's NaN-column / mean / std / centering passes (array.py:191-215)
+        run.  `'device'`: on the GPU over the uploaded raw field - column means in float64 - and the centered field stays
+        resident for solve(); the host copy `_fields` is fetched on first use.  `'host'`: the reference's numpy path
+        (bit-identical means for float32 input).  Default (None): `'device'` when a GPU is visible and the fields are
+        plain real float32 / float64 arrays of one dtype, `'host'` otherwise (XMCA_PREPROCESS=host|device overrides)."""
+        if preprocess is None:
+            preprocess = os.environ.get('XMCA_PREPROCESS') or 'auto'
+        if preprocess not in ('host', 'device', 'auto'):
             raise ValueError("preprocess must be 'host' or 'device'")
+        if preprocess == 'auto':
+            preprocess = 'device' if (handle is not None or _gpu_visible()) else 'host'
         if len(fields) > 2:
             raise ValueError("Too many fields. Pass 1 or 2 fields.")
         if len(fields) == 2 and fields[0].shape[0] != fields[1].shape[0]:
@@ -1097,71 +1101,23 @@ class MCA:
         import yaml
         print(yaml.dump({k: str(v) for k, v in self._analysis.items()}, sort_keys=False, default_flow_style=False))
 
-    # ------------------------------------------------------------------------------------------
-    # plotting (array.py:1430-1600) - matplotlib only, imported lazily
-    # ------------------------------------------------------------------------------------------
-    def plot(self, mode, threshold=0, phase_shift=0, cmap_eof=None, cmap_phase=None, figsize=(8.3, 5.0)):
-        """PC, EOF (amplitude) and, for complex models, phase of `mode` for each field."""
-        import matplotlib.pyplot as plt
-        cplx = self._analysis['is_complex']
-        pcs = self.pcs(mode, scaling='max', phase_shift=phase_shift)
-        maps = self.spatial_amplitude(mode, scaling='max') if cplx else self.eofs(mode, scaling='max')
-        phases = self.spatial_phase(mode, phase_shift=phase_shift)
-        var = self.explained_variance(mode)[-1]
-        cmap_eof = cmap_eof or ('Blues' if cplx else 'RdBu_r')
-        cmap_phase = cmap_phase or 'twilight'
-        rng = [0, 1] if cplx else [-1, 0, 1]
-        n_rows, n_cols = len(pcs) + 1, 3 if cplx else 2
-        fig = plt.figure(figsize=figsize, dpi=150)
-        fig.subplots_adjust(hspace=0.1, wspace=.1, left=0.25)
-        gs = fig.add_gridspec(n_rows, n_cols, height_ratios=[1] * (n_rows - 1) + [0.05])
-        axes = {'pc': [], 'eof': [], 'phase': []}
-        for i, k in enumerate(pcs):
-            name = boldify_str(self._field_names[k].replace('_', ' '))
-            amp = maps[k][..., -1]
-            amp = np.where(abs(amp) >= threshold, amp, np.nan)
-            ax = fig.add_subplot(gs[i, 0])
-            ax.plot(pcs[k][:, -1].real)
-            ax.set_ylim(-1.2, 1.2)
-            ax.set_yticks([-1, 0, 1])
-            ax.set_ylabel(name, fontweight='bold')
-            for side in ('right', 'top'):
-                ax.spines[side].set_visible(False)
-            axes['pc'].append(ax)
-            ax = fig.add_subplot(gs[i, 1])
-            img = ax.imshow(np.atleast_2d(amp), origin='lower', vmin=rng[0], vmax=rng[-1], cmap=cmap_eof)
-            axes['eof'].append(ax)
-            if cplx:
-                ph = np.where(abs(amp) >= threshold, phases[k][..., -1], np.nan)
-                ax = fig.add_subplot(gs[i, 2])
-                pimg = ax.imshow(np.atleast_2d(ph), origin='lower', vmin=-np.pi, vmax=np.pi, cmap=cmap_phase)
-                axes['phase'].append(ax)
-        axes['pc'][0].set_title(boldify_str(r'PC {:d} ({:.1f} \%)'.format(mode, var)), fontweight='bold')
-        axes['eof'][0].set_title(boldify_str('Amplitude' if cplx else 'EOF'), fontweight='bold')
-        cb = fig.add_subplot(gs[-1, 1])
-        plt.colorbar(img, cb, orientation='horizontal')
-        cb.xaxis.set_ticks(rng)
-        if cplx:
-            axes['phase'][0].set_title(boldify_str('Phase'), fontweight='bold')
-            cbp = fig.add_subplot(gs[-1, 2])
-            plt.colorbar(pimg, cbp, orientation='horizontal')
-            cbp.xaxis.set_ticks([-3.14, 0, 3.14])
-            cbp.set_xticklabels([r'-$\pi$', '0', r'$\pi$'])
-        for ax in axes['eof'] + axes['phase']:
-            ax.set_aspect('auto')
-            ax.xaxis.set_visible(False)
-            ax.yaxis.set_visible(False)
-        if len(pcs) == 2:
-            axes['pc'][0].xaxis.set_visible(False)
-            axes['pc'][0].spines['bottom'].set_visible(False)
-        return fig, axes
 
-    def save_plot(self, mode, path=None, plot_kwargs={}, save_kwargs={}):
-        """Create the figure of `plot(mode)` and save it."""
-        import matplotlib.pyplot as plt
-        fig, _ = self.plot(mode=mode, **plot_kwargs)
-        fig.subplots_adjust(left=0.06)
-        plt.savefig('mode{:}.png'.format(mode) if path is None else path, **save_kwargs)
+def _gpu_visible():
+    try:
+        return _hip.load_library().xmca_device_count() > 0
+    except Exception:
+        return False
+
+
+def secure_str(string):
+    """file name form of a field name (info.xmca / netCDF names of save_analysis, array.py:1602-1627)"""
+    return string.lower().replace(' ', '_')
+
+
+def wrap_str(string):
+    """'# '-prefixed comment block (header of info.xmca, array.py:1629-1640)"""
+    import textwrap
+    return textwrap.indent(textwrap.fill(string, width=80), '# ')
 
 
 def _real_dtype(dt):

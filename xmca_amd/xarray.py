@@ -10,8 +10,7 @@ import os
 
 import numpy as np
 
-from .array import MCA
-from .tools.text import secure_str
+from .array import MCA, secure_str
 
 
 def _xr():
@@ -25,7 +24,7 @@ def _xr():
 class xMCA(MCA):
     """MCA / EOF analysis of one or two `xarray.DataArray` (time, lat, lon)."""
 
-    def __init__(self, *fields, handle=None):
+    def __init__(self, *fields, handle=None, preprocess=None):
         xr = _xr()
         if len(fields) > 2:
             raise ValueError("Too many fields. Pass 1 or 2 fields.")
@@ -37,7 +36,7 @@ class xMCA(MCA):
         for key, field in zip(['left', 'right'], fields):
             self._field_dims[key] = field.dims
             self._field_coords[key] = field.coords
-        super().__init__(*[f.values for f in fields], handle=handle)
+        super().__init__(*[f.values for f in fields], handle=handle, preprocess=preprocess)
 
     # ------------------------------------------------------------------ scaling incl. coslat weights
     def _coslat_weights(self, k):
@@ -246,10 +245,6 @@ class xMCA(MCA):
         MCA.load_analysis(self, path=path, fields=fields, eofs=eofs, singular_values=singular_values)
         if self._analysis['is_coslat_corrected']:
             self.apply_coslat()
-
-    def plot(self, *args, **kwargs):
-        """Map plots need cartopy (not part of this build); the plain image plot of the array class is used instead."""
-        return MCA.plot(_NumpyView(self), *args, **kwargs)
 
 
 class _NumpyView:
