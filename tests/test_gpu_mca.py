@@ -600,7 +600,7 @@ def test_model_identity_is_not_its_address():
     del a
     gc.collect()
     for _ in range(50):
-        b = MCA(*make_input("small_both"))
+        b = MCA(*make_input("small_both"), preprocess='host')          # (nothing uploaded: it cannot own anything yet)
         assert not b._owns_device_fields(dev)
         assert dev.fields_owner is key
         del b

@@ -89,7 +89,9 @@ def test_facade_wraps_the_array_class(cplx):
 
     back = xm.fields(original_scale=True)
     assert back['left'].dims == ('time', 'lat', 'lon')
-    assert np.allclose(back['left'].values.real, left.values, rtol=1e-9, atol=1e-9, equal_nan=True)
+    # (apply_coslat weights with sqrt(cos(lat) + 1e-6), the inverse scaling divides by sqrt(cos(lat)): xarray.py:167-181 vs
+    #  :110-126 - the reference's own round-trip test uses rtol = 1e-3, test_integration_xarray.py:284-341)
+    assert np.allclose(back['left'].values.real, left.values, rtol=1e-4, atol=1e-4, equal_nan=True)
 
     runs = xm.rule_n(5, seed=3)
     ref_runs = m.rule_n(5, seed=3)
@@ -106,4 +108,6 @@ def test_facade_wraps_the_array_class(cplx):
     first = xr.DataArray(left.values[:10], dims=left.dims, coords={'time': left.coords['time'].values[:10],
                                                                    'lat': left.coords['lat'].values, 'lon': left.coords['lon'].values})
     new = xm.predict(first, n=3)
-    assert new['left'].dims == ('time', 'mode') and np.allclose(new['left'].values, pcs['left'].values[:10, :3], rtol=1e-6, atol=1e-8)
+    assert new['left'].dims == ('time', 'mode') and new['left'].shape == (10, 3)
+    if not cplx:          # (a complex model's PCs belong to the analytic signal of the whole series, not to 10 real time steps)
+        assert np.allclose(new['left'].values, pcs['left'].values[:10, :3], rtol=1e-6, atol=1e-8)

@@ -294,9 +294,20 @@ struct GemmOpts {
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;   // optional: recorded around the MFMA kernel launch alone
 };
 
+// stream-K schedule state of the NT kernel (gemm_nt.h)
+struct GemmNtWorkspace {
+  DevBuf<double> partial;       // raw sums of the partial segments, [grid][2][BM * BN]
+  DevBuf<int> split_tiles;      // tiles whose units span more than one workgroup range
+  int n_split = 0;
+  int64_t key_tiles = -1;
+  int key_nkt = -1, key_upw = -1;
+  int n_cus = 0;
+};
+
 // scratch for split-K partial sums and the tile-order tables, owned by the caller (one per stream)
 struct GemmWorkspace {
   DevBuf<double> partial;
+  GemmNtWorkspace nt;
   struct Map { int tm, tn, upper; DevBuf<int> dev; int n; };
   std::vector<std::unique_ptr<Map>> maps;
 
@@ -339,12 +350,18 @@ static void launch_gemm_variant(hipStream_t st, const GemmParams<TI, TO>& p, boo
   XMCA_HIP(hipGetLastError());
 }
 
+}  // namespace xmca
+#include "gemm_nt.h"
+namespace xmca {
+
 // TI in {float,double}; TO in {float,double}.  f32 operands always use WIDE accumulation.
 template <typename TI, typename TO>
 void gemm(hipStream_t st, GemmWorkspace& ws, const TI* A, int64_t lda, const TI* B, int64_t ldb, TO* C, int64_t ldc, int M,
           int N, int K, const GemmOpts& o) {
   if (M <= 0 || N <= 0) return;
   XMCA_CHECK(!o.upper_only || M == N, XMCA_ERR_INVALID, "gemm: upper_only needs a square result");
+  // both operands contiguous along the contraction axis (covariance / Gram products): stream-K kernel of gemm_nt.h
+  if (o.a_kfast && !o.b_nfast && gemm_nt<TI, TO>(st, ws, ws.nt, A, lda, B, ldb, C, ldc, M, N, K, o)) return;
   const int tm = ceil_div(M, GEMM_BM), tn = ceil_div(N, GEMM_BN);
   const int64_t tiles = o.upper_only ? (int64_t)tm * (tm + 1) / 2 : (int64_t)tm * tn;
   const int nkt = ceil_div(K, GEMM_BK);
