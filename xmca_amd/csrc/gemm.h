@@ -308,23 +308,25 @@ struct GemmNtWorkspace {
 struct GemmWorkspace {
   DevBuf<double> partial;
   GemmNtWorkspace nt;
-  struct Map { int tm, tn, upper; DevBuf<int> dev; int n; };
+  struct Map { int tm, tn, upper, ratio; DevBuf<int> dev; int n; };
   std::vector<std::unique_ptr<Map>> maps;
 
   // Tiles are enumerated in 8 x 8 super-blocks: the ~64 workgroups that share one XCD's L2 at a time then touch only
   // 8 + 8 operand panels, so each panel slice is fetched from HBM / Infinity Cache once per XCD and reused from L2.
-  const Map& tile_map(hipStream_t st, int tm, int tn, bool upper) {
+  // `ratio` = tile rows / tile columns (rectangular tiles of gemm_big.h): with `upper`, tile (i, j) is kept when it reaches
+  // the diagonal or lies above it, j >= ratio * i.
+  const Map& tile_map(hipStream_t st, int tm, int tn, bool upper, int ratio = 1) {
     for (auto& m : maps)
-      if (m->tm == tm && m->tn == tn && m->upper == (int)upper) return *m;
+      if (m->tm == tm && m->tn == tn && m->upper == (int)upper && m->ratio == ratio) return *m;
     constexpr int G = 8;
     std::vector<int> order;
     for (int si = 0; si < tm; si += G)
-      for (int sj = upper ? si : 0; sj < tn; sj += G)
+      for (int sj = upper ? (si * ratio) / G * G : 0; sj < tn; sj += G)
         for (int i = si; i < std::min(si + G, tm); ++i)
           for (int j = sj; j < std::min(sj + G, tn); ++j)
-            if (!upper || j >= i) order.push_back((i << 16) | j);
+            if (!upper || j >= ratio * i) order.push_back((i << 16) | j);
     auto m = std::make_unique<Map>();
-    m->tm = tm; m->tn = tn; m->upper = upper; m->n = (int)order.size();
+    m->tm = tm; m->tn = tn; m->upper = upper; m->ratio = ratio; m->n = (int)order.size();
     XMCA_HIP(hipMemcpyAsync(m->dev.ensure(order.size()), order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice, st));
     XMCA_HIP(hipStreamSynchronize(st));
     maps.push_back(std::move(m));

@@ -26,7 +26,7 @@ struct NtCfg;
 #define XMCA_NT_F64_WGS 1
 #endif
 #ifndef XMCA_NT_F32_WGS
-#define XMCA_NT_F32_WGS 1
+#define XMCA_NT_F32_WGS 2
 #endif
 template <>
 struct NtCfg<double> { static constexpr int PITCH = GEMM_BK + 2, WGS_PER_CU = XMCA_NT_F64_WGS, NBUF = 3 - WGS_PER_CU, MINW = 2 * WGS_PER_CU; };
@@ -254,10 +254,14 @@ __global__ __launch_bounds__(256) void gemm_nt_fixup_kernel(const double* __rest
 template <typename TI, typename TO>
 bool gemm_nt(hipStream_t st, GemmWorkspace& ws, GemmNtWorkspace& nws, const TI* A, int64_t lda, const TI* B, int64_t ldb, TO* C,
              int64_t ldc, int M, int N, int K, const GemmOpts& o) {
-  // measured on MI355X (scripts/gemm_nt_check.py): ahead of the general kernel on dense shapes (4096^3 f64 67 % vs 60 %, f32 63 %
-  // vs 51 % of peak) and behind it on the long-K Gram products of the path (C2 2.2 vs 1.9 ms, C5 31 vs 20 ms) - one
-  // workgroup per CU does not cover its own barriers there.  Opt-in (XMCA_GEMM_NT=1) until it wins on those as well.
-  static const bool enabled = [] { const char* e = std::getenv("XMCA_GEMM_NT"); return e && e[0] == '1'; }();
+  // Measured on MI355X (scripts/gemm_nt_check.py, Gram products of the path): float32 fields, two workgroups per CU - as
+  // fast as the general kernel (C5 20.1 vs 20.0 ms, C3 5.4 vs 5.5 ms) with a tenth of its partial-sum traffic (C5: 0.13
+  // instead of 1.47 GB) -> default for float32.  float64: the two-per-CU build spills (292 bytes per lane, 2.5 vs 1.9 ms
+  // at C2) and one workgroup per CU does not cover its own barriers (2.2 ms) -> general kernel unless XMCA_GEMM_NT=1.
+  // Negative results kept out of the tree: a 256 x 128 block tile (one workgroup per CU, 256 VGPRs) was 0-25 % slower
+  // than the 128 x 128 kernel on every shape of the path; the field stored transposed (TN) gains 3-7 %.
+  static const int mode = [] { const char* e = std::getenv("XMCA_GEMM_NT"); return e ? std::atoi(e) : -1; }();   // -1: float32 only
+  const bool enabled = mode == 1 || (mode == -1 && std::is_same<TI, float>::value);
   if (!enabled || K <= 0 || o.force_splits > 0) return false;
   if (nws.n_cus == 0) {
     int dev = 0, n = 256;
