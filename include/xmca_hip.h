@@ -28,7 +28,7 @@ extern "C" {
 #define XMCA_ERR_HIP (-2)            /* HIP runtime failure                            -> RuntimeError          */
 #define XMCA_ERR_NOT_CONVERGED (-3)  /* Varimax hit max_iter (rotation.py:66-71)       -> RuntimeError          */
 #define XMCA_ERR_STATE (-4)          /* call order (e.g. vectors before solve)         -> RuntimeError          */
-#define XMCA_ERR_UNSUPPORTED (-5)    /* outside device limits (e.g. n_rot too large)   -> NotImplementedError   */
+#define XMCA_ERR_UNSUPPORTED (-5)    /* outside device limits                          -> NotImplementedError   */
 #define XMCA_ERR_NUMERIC (-6)        /* NaN / singular matrix (array.py:575-578)       -> numpy LinAlgError     */
 
 #define XMCA_F32 0

@@ -63,8 +63,6 @@ def test_argument_errors(hip):
         hip.rotate_loadings(A, n_left=10, power=0)
     with pytest.raises(ValueError):
         hip.rotate_loadings(A[:, :1], n_left=10)
-    with pytest.raises(NotImplementedError):
-        hip.rotate_loadings(np.ones((100, 65)) + np.arange(65), n_left=10)
 
 
 def test_zero_row_is_linalg_error(hip):
@@ -114,3 +112,29 @@ def test_varimax_gamma_family_matches_oracle(hip, tag, gamma):
     B, R = varimax(A, gamma=gamma, handle=hip)
     assert hip.last_iters == n_iter
     assert _rel(R, Ro) < TOL and _rel(B, Bo) < TOL
+
+
+@pytest.mark.parametrize("n,p,cplx,power", [(900, 70, False, 1), (900, 70, False, 2), (700, 52, True, 1), (700, 50, True, 3), (1500, 130, False, 1)])
+def test_more_modes_than_the_fused_kernels_hold(hip, n, p, cplx, power):
+    """The reference has no limit on n_rot.  Beyond 64 real / 48 complex modes the fused single-workgroup kernels do not
+    fit their LDS image; the GEMM-based path (Rotator::run_generic) takes over: same trajectory, same stop iteration,
+    R / Phi / B against the numpy restatement of rotation.py:15-149."""
+    from oracle import ref_numpy as O
+    rng = np.random.default_rng(100 + p)
+    L = 0.12 * rng.standard_normal((n, p))
+    w = n // p
+    for j in range(p):
+        L[j * w:(j + 1) * w, j] += np.hanning(w) * (3.0 - 1.5 * j / p)
+    if cplx:
+        L = L * np.exp(1j * rng.uniform(0, 2 * np.pi, (n, 1)) * 0.3) + 0.04j * rng.standard_normal((n, p))
+        M = rng.standard_normal((p, p)) + 1j * rng.standard_normal((p, p))
+    else:
+        M = rng.standard_normal((p, p))
+    Q, _ = np.linalg.qr(M)
+    A = L @ Q
+    Bo, Ro, Phio, n_iter = O.promax(A, power)
+    out = hip.rotate_loadings(A, n_left=n // 3, power=power, tol=1e-8, want_B=True)
+    assert out["n_iter"] == n_iter
+    assert _rel(out["R"], Ro) < 1e-6 and _rel(out["Phi"], Phio) < 1e-6 and _rel(out["B"], Bo) < 1e-6
+    assert _rel(out["norm_left"], np.linalg.norm(Bo[:n // 3], axis=0)) < 1e-6
+    assert _rel(out["norm_right"], np.linalg.norm(Bo[n // 3:], axis=0)) < 1e-6

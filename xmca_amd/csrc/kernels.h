@@ -81,6 +81,12 @@ __global__ void scale_kernel(double* __restrict__ re, double* __restrict__ im, i
   }
 }
 
+// G[i][i] += v
+__global__ void add_diag_kernel(double* __restrict__ G, int64_t ld, int n, double v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) G[(int64_t)i * ld + i] += v;
+}
+
 // Ht[t][s] = col[(t - s) mod T]  (circulant operator from its first column)
 template <typename TO>
 __global__ void circulant_kernel(const double* __restrict__ col, int T, TO* __restrict__ out) {

@@ -88,6 +88,77 @@ __global__ void rot_import_loadings_kernel(const double* __restrict__ L, int64_t
   }
 }
 
+// ---- element-wise / row kernels of the GEMM-based rotation path (any number of modes; Rotator::run_generic) ----------
+// out[k] = sum_n |Zt[k][n]|^2  (or max_n |Zt[k][n]| with `take_max`); one workgroup per mode row
+__global__ __launch_bounds__(256) void rot_row_reduce_kernel(const double* __restrict__ Zr, const double* __restrict__ Zi, int64_t N,
+                                                             int take_max, double* __restrict__ out) {
+  __shared__ double red[4];
+  const int64_t k = blockIdx.x;
+  double acc = 0.0;
+  for (int64_t n = threadIdx.x; n < N; n += 256) {
+    const double a = Zr[k * N + n], b = Zi ? Zi[k * N + n] : 0.0;
+    const double v = a * a + b * b;
+    acc = take_max ? fmax(acc, v) : acc + v;
+  }
+  if (take_max) {
+    for (int o = 32; o > 0; o >>= 1) acc = fmax(acc, __shfl_xor(acc, o));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    acc = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    if (threadIdx.x == 0) out[k] = sqrt(acc);
+  } else {
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[k] = red[0] + red[1] + red[2] + red[3];
+  }
+}
+// Varimax: Z <- (|Z|^2 - gamma c_k / N) Z   (rotation.py:56-57), in place on the mode-major planes
+__global__ void rot_w_kernel(double* __restrict__ Zr, double* __restrict__ Zi, int64_t N, int p, const double* __restrict__ c,
+                             double gamma) {
+  const int64_t tot = (int64_t)p * N;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(e / N);
+    const double a = Zr[e], b = Zi ? Zi[e] : 0.0;
+    const double f = a * a + b * b - gamma * (c[k] / (double)N);
+    Zr[e] = f * a;
+    if (Zi) Zi[e] = f * b;
+  }
+}
+// Promax target (rotation.py:121-124): P = Xn |Xn|^(power - 1) with Xn = X / colmax, into (Pr, Pi)
+__global__ void rot_target_kernel(const double* __restrict__ Xr, const double* __restrict__ Xi, int64_t N, int p,
+                                  const double* __restrict__ colmax, double power, double* __restrict__ Pr, double* __restrict__ Pi) {
+  const int64_t tot = (int64_t)p * N;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(e / N);
+    const double a = Xr[e] / colmax[k], b = Xi ? Xi[e] / colmax[k] : 0.0;
+    const double f = pow(sqrt(a * a + b * b), power - 1.0);
+    Pr[e] = f * a;
+    if (Pi) Pi[e] = f * b;
+  }
+}
+// rows of X (mode-major p x N planes) <- X[:, n] * w[n] / ||X[:, n]|| (the rotated loadings re-normalised per grid point
+// and weighted by the original row norms: h2-weighted X of the block-norm Grams); `renorm_only`: w is ignored
+__global__ void rot_point_scale_kernel(double* __restrict__ Xr, double* __restrict__ Xi, int64_t N, int p, const double* __restrict__ w,
+                                       int renorm_only) {
+  for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
+    double acc = 0.0;
+    for (int k = 0; k < p; ++k) {
+      const double a = Xr[(int64_t)k * N + n], b = Xi ? Xi[(int64_t)k * N + n] : 0.0;
+      acc += a * a + b * b;
+    }
+    const double nrm = sqrt(acc);
+    // renorm_only: X / |X_n| ;  otherwise h2 X_normalised = (h |(AR)_n|) (AR)_n / |(AR)_n| = h (A R)_n
+    const double f = renorm_only ? 1.0 / nrm : w[n];
+    for (int k = 0; k < p; ++k) {
+      Xr[(int64_t)k * N + n] *= f;
+      if (Xi) Xi[(int64_t)k * N + n] *= f;
+    }
+  }
+}
+
 // Generic single-pass accumulation over grid points (one p x p result per launch).
 //   MODE 0 (Varimax step): Z = A R ;  W = |Z|^2 Z - Z c / N ;             out = A^H W
 //   MODE 1 (Gram)        : out = A^H A

@@ -793,7 +793,11 @@ class Rotator {
   hipStream_t st;
   StageTimer& tm;
   double gamma = 1.0;   // Varimax family parameter (rotation.py:15,56-57): 1 = Varimax (what MCA.rotate uses), 0 = Quartimax
+  GemmWorkspace* gws = nullptr;   // only the GEMM-based path (more modes than the fused kernels hold, run_generic) needs these
+  EvdWorkspace* ews = nullptr;
   Rotator(hipStream_t s, StageTimer& t) : st(s), tm(t) {}
+  Rotator(hipStream_t s, StageTimer& t, GemmWorkspace& g, EvdWorkspace& e) : st(s), tm(t), gws(&g), ews(&e) {}
+  static bool fused_fits(int p, bool cplx) { return p <= rot_max_modes(cplx); }
 
   static int pick_nwg(int64_t N) {
     const int64_t nb = (N + ROT_PB - 1) / ROT_PB;
@@ -820,9 +824,9 @@ class Rotator {
   }
 
   void alloc(RotationDevice& d, int64_t N, int64_t Nleft, int p, bool cplx) {
-    XMCA_CHECK(p >= 2 && p <= rot_max_modes(cplx), XMCA_ERR_UNSUPPORTED,
-               "rotate: n_rot = " + std::to_string(p) + " exceeds the device limit of " + std::to_string(rot_max_modes(cplx)) +
-                   (cplx ? " (complex)" : " (real)") + " rotated modes");
+    XMCA_CHECK(p >= 2, XMCA_ERR_INVALID, "rotate: n_rot must be > 1");
+    XMCA_CHECK(fused_fits(p, cplx) || (gws && ews), XMCA_ERR_UNSUPPORTED,
+               "rotate: n_rot = " + std::to_string(p) + " needs the GEMM-based path (no workspace given)");
     d.N = N; d.Nleft = Nleft; d.p = p; d.cplx = cplx;
     d.nwg = pick_nwg(N);
     d.A.ensure((size_t)p * N, cplx);
@@ -844,6 +848,7 @@ class Rotator {
   void run(RotationDevice& d, int power, double tol, int max_iter, RotateResult& res, double* B_out_dev, bool varimax_only) {
     const int p = d.p;
     res.p = p; res.cplx = CPLX;
+    if (!fused_fits(p, CPLX)) { run_generic<CPLX>(d, power, tol, max_iter, res, B_out_dev, varimax_only); return; }
     tm.begin("varimax");
     accum<CPLX, 1, 0>(d, 1.0, d.A0.r(), d.A0.i(CPLX));
     hipLaunchKernelGGL((varimax_step_kernel<CPLX>), dim3(1), dim3(256), 0, st, d.part_r.get(), CPLX ? d.part_i.get() : nullptr, d.nwg,
@@ -975,6 +980,14 @@ class Rotator {
     accum<CPLX, 2, 3>(d, (double)power, d.acc.r(), d.acc.i(CPLX)); fetch(SR);
     tm.end();
 
+    finish_promax<CPLX>(d, Rv, XX, XP, SL, SR, res, B_out_dev);
+  }
+
+  // p x p tail of Promax on the host (rotation.py:128-147) from the four p x p sums of the N-sized passes
+  template <bool CPLX>
+  void finish_promax(RotationDevice& d, const SmallMat& Rv, const SmallMat& XX, const SmallMat& XP, const SmallMat& SL, const SmallMat& SR,
+                     RotateResult& res, double* B_out_dev) {
+    const int p = d.p;
     // L = inv(X^H X) X^H P ; sigma = diag(inv(L^H L)) ; L <- L sqrt(sigma) ; R <- R L ; Phi = L^-1 L^-H
     SmallMat XXinv, L, LLinv, Linv;
     XMCA_CHECK(XX.inverse(XXinv), XMCA_ERR_NUMERIC, "promax: X^H X is singular");
@@ -999,6 +1012,125 @@ class Rotator {
       res.norm_right[k] = std::sqrt(std::max(nr(k, k).real(), 0.0));
     }
     if (B_out_dev) apply<CPLX>(d, Rf, B_out_dev);
+  }
+
+  // -------------------------------------------------------------------------------------------------------------
+  // GEMM-based Varimax / Promax for ANY number of modes (the reference has no limit on n_rot; the fused kernels keep
+  // R, a 64-point slab of Z and of W in the LDS of one workgroup: <= 64 real / 48 complex modes).  Per iteration
+  // (rotation.py:52-64):  Zt = R^T A (p x N GEMM), c_k = sum_n |Zt_kn|^2, W = (|Z|^2 - gamma c / N) Z in place,
+  // G = A^H W (p x p GEMM), and the unitary polar factor of G through the Hermitian EVD of G^H G = Q L Q^H:
+  // R = G Q L^-1/2 Q^H, polished by one Newton-Schulz step (the squared conditioning of G^H G), d = sum sqrt(l_i).
+  // The stopping rule runs on the host (one synchronisation per iteration, which the EVD needs anyway).  ~2 ms per
+  // iteration instead of ~20 us: a fallback for unusual n_rot, not a fast path.
+  // -------------------------------------------------------------------------------------------------------------
+  template <bool CPLX>
+  void run_generic(RotationDevice& d, int power, double tol, int max_iter, RotateResult& res, double* B_out_dev, bool varimax_only) {
+    const int p = d.p;
+    const int64_t N = d.N;
+    const size_t pp = (size_t)p * p;
+    CPlanes Zt, G, H, Qh, T1, R2;
+    Zt.ensure((size_t)p * N, CPLX);
+    G.ensure(pp, CPLX); H.ensure(pp, CPLX); Qh.ensure(pp, CPLX); T1.ensure(pp, CPLX); R2.ensure(pp, CPLX);
+    DevBuf<double> cvec, isq;
+    cvec.ensure((size_t)p);
+    isq.ensure((size_t)p);
+    std::vector<double> eye(pp, 0.0), lam, inv_s((size_t)p);
+    for (int i = 0; i < p; ++i) eye[(size_t)i * p + i] = 1.0;
+    XMCA_HIP(hipMemcpyAsync(d.R.r(), eye.data(), sizeof(double) * pp, hipMemcpyHostToDevice, st));
+    if (CPLX) XMCA_HIP(hipMemsetAsync(d.R.im.get(), 0, sizeof(double) * pp, st));
+    auto rotate_A = [&](CPlanes& out) {     // out = R^T A  (p x N, mode-major like A)
+      cgemm<double>(st, *gws, d.R.r(), d.R.i(CPLX), p, false, false, d.A.r(), d.A.i(CPLX), N, true, false, out.r(), out.i(CPLX), N, p, (int)N,
+                    p, 1.0, nullptr, nullptr, false);
+    };
+    // C = X^H Y over the grid points [n0, n1):  C[j][k] = sum_n conj(Xt[j][n]) Yt[k][n]
+    auto gram = [&](const CPlanes& X, const CPlanes& Y, int64_t n0, int64_t n1, CPlanes& C) {
+      cgemm<double>(st, *gws, X.r() + n0, CPLX ? X.im.get() + n0 : nullptr, N, true, true, Y.r() + n0, CPLX ? Y.im.get() + n0 : nullptr, N, false,
+                    false, C.r(), C.i(CPLX), p, p, p, (int)(n1 - n0), 1.0, nullptr, nullptr, false);
+    };
+    tm.begin("varimax");
+    double dsum = 0.0;
+    res.iters = 0; res.converged = false; res.nan = false;
+    for (int it = 0; it < max_iter; ++it) {
+      const double d_old = dsum;
+      rotate_A(Zt);
+      hipLaunchKernelGGL(rot_row_reduce_kernel, dim3(p), dim3(256), 0, st, Zt.r(), Zt.i(CPLX), N, 0, cvec.get());
+      hipLaunchKernelGGL(rot_w_kernel, ew_grid((int64_t)p * N), dim3(EW_BLOCK), 0, st, Zt.r(), Zt.i(CPLX), N, p, cvec.get(), gamma);
+      gram(d.A, Zt, 0, N, G);
+      // polar factor of G
+      cgemm<double>(st, *gws, G.r(), G.i(CPLX), p, false, true, G.r(), G.i(CPLX), p, true, false, H.r(), H.i(CPLX), p, p, p, p, 1.0, nullptr,
+                    nullptr, true);
+      hermitian_evd(st, *ews, H.r(), H.i(CPLX), p, p, lam, nullptr, Qh.r(), Qh.i(CPLX), p);
+      dsum = 0.0;
+      bool bad = false;
+      for (int i = 0; i < p; ++i) {
+        const double sv = std::sqrt(std::max(lam[i], 0.0));
+        dsum += sv;
+        if (!(sv > 1e-14 * std::sqrt(std::max(lam[0], 0.0))) || !std::isfinite(sv)) bad = true;
+        inv_s[i] = 1.0 / sv;
+      }
+      res.iters = it + 1;
+      if (bad || !(dsum == dsum)) { res.nan = true; break; }
+      XMCA_HIP(hipMemcpyAsync(isq.get(), inv_s.data(), sizeof(double) * p, hipMemcpyHostToDevice, st));
+      // T1 = G Q diag(1/s)  (Q[l][i] = conj(Qh[i][l]));  R = T1 Q^H  (Q^H[i][k] = Qh[i][k])
+      cgemm<double>(st, *gws, G.r(), G.i(CPLX), p, true, false, Qh.r(), Qh.i(CPLX), p, false, true, T1.r(), T1.i(CPLX), p, p, p, p, 1.0, nullptr,
+                    isq.get(), false);
+      cgemm<double>(st, *gws, T1.r(), T1.i(CPLX), p, true, false, Qh.r(), Qh.i(CPLX), p, true, false, R2.r(), R2.i(CPLX), p, p, p, p, 1.0, nullptr,
+                    nullptr, false);
+      // one Newton-Schulz step: R = R2 (1.5 I - 0.5 R2^H R2)
+      cgemm<double>(st, *gws, R2.r(), R2.i(CPLX), p, false, true, R2.r(), R2.i(CPLX), p, true, false, H.r(), H.i(CPLX), p, p, p, p, -0.5, nullptr,
+                    nullptr, true);
+      hipLaunchKernelGGL(add_diag_kernel, dim3(ceil_div(p, 256)), dim3(256), 0, st, H.r(), (int64_t)p, p, 1.5);
+      cgemm<double>(st, *gws, R2.r(), R2.i(CPLX), p, true, false, H.r(), H.i(CPLX), p, true, false, d.R.r(), d.R.i(CPLX), p, p, p, p, 1.0, nullptr,
+                    nullptr, false);
+      XMCA_HIP(hipGetLastError());
+      XMCA_HIP(hipStreamSynchronize(st));       // inv_s is reused by the next iteration
+      if (std::fabs(dsum - d_old) / dsum < tol) { res.converged = true; break; }      // rotation.py:62
+    }
+    tm.end();
+    res.last_d = dsum;
+    if (!res.converged) return;
+
+    std::vector<double> Rr(pp), Ri(pp, 0.0);
+    XMCA_HIP(hipMemcpyAsync(Rr.data(), d.R.r(), sizeof(double) * pp, hipMemcpyDeviceToHost, st));
+    if (CPLX) XMCA_HIP(hipMemcpyAsync(Ri.data(), d.R.im.get(), sizeof(double) * pp, hipMemcpyDeviceToHost, st));
+    XMCA_HIP(hipStreamSynchronize(st));
+    SmallMat Rv(p);
+    for (size_t e = 0; e < pp; ++e) Rv.a[e] = cd(Rr[e], Ri[e]);
+    if (varimax_only) {
+      res.R = Rv.a;
+      res.Phi = SmallMat::eye(p).a;
+      if (B_out_dev) apply<CPLX>(d, Rv, B_out_dev);
+      return;
+    }
+    tm.begin("promax");
+    // X = row-normalised (A R), B = h (A R) per grid point (rotation.py:115-117), target P (:121-124), then the four sums
+    CPlanes Bs, Pt, C;
+    Bs.ensure((size_t)p * N, CPLX); Pt.ensure((size_t)p * N, CPLX); C.ensure(pp, CPLX);
+    rotate_A(Zt);
+    XMCA_HIP(hipMemcpyAsync(Bs.r(), Zt.r(), sizeof(double) * (size_t)p * N, hipMemcpyDeviceToDevice, st));
+    if (CPLX) XMCA_HIP(hipMemcpyAsync(Bs.im.get(), Zt.im.get(), sizeof(double) * (size_t)p * N, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(rot_point_scale_kernel, ew_grid(N), dim3(EW_BLOCK), 0, st, Bs.r(), Bs.i(CPLX), N, p, d.h.get(), 0);
+    hipLaunchKernelGGL(rot_point_scale_kernel, ew_grid(N), dim3(EW_BLOCK), 0, st, Zt.r(), Zt.i(CPLX), N, p, (const double*)nullptr, 1);
+    hipLaunchKernelGGL(rot_row_reduce_kernel, dim3(p), dim3(256), 0, st, Zt.r(), Zt.i(CPLX), N, 1, cvec.get());
+    hipLaunchKernelGGL(rot_target_kernel, ew_grid((int64_t)p * N), dim3(EW_BLOCK), 0, st, Zt.r(), Zt.i(CPLX), N, p, cvec.get(), (double)power,
+                       Pt.r(), Pt.i(CPLX));
+    XMCA_HIP(hipGetLastError());
+    auto fetch = [&](SmallMat& M) {
+      std::vector<double> r(pp), i(pp, 0.0);
+      XMCA_HIP(hipMemcpyAsync(r.data(), C.r(), sizeof(double) * pp, hipMemcpyDeviceToHost, st));
+      if (CPLX) XMCA_HIP(hipMemcpyAsync(i.data(), C.im.get(), sizeof(double) * pp, hipMemcpyDeviceToHost, st));
+      XMCA_HIP(hipStreamSynchronize(st));
+      M = SmallMat(p);
+      for (size_t e = 0; e < pp; ++e) M.a[e] = cd(r[e], i[e]);
+    };
+    SmallMat XX, XP, SL, SR;
+    gram(Zt, Zt, 0, N, C); fetch(XX);
+    gram(Zt, Pt, 0, N, C); fetch(XP);
+    SL = SmallMat(p); SR = SmallMat(p);
+    if (d.Nleft > 0) { gram(Bs, Bs, 0, d.Nleft, C); fetch(SL); }
+    if (d.Nleft < N) { gram(Bs, Bs, d.Nleft, N, C); fetch(SR); }
+    tm.end();
+    finish_promax<CPLX>(d, Rv, XX, XP, SL, SR, res, B_out_dev);
   }
 
   // B = h (A M)  -> N x p row-major (interleaved complex) on the device

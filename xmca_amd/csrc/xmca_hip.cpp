@@ -420,7 +420,7 @@ struct ReplicateRunner {
   ReplicateRunner(xmca_handle* h_, int64_t T_, int64_t Nx, int64_t Ny, int n_fields_, const double* ht_host, int rotated_, int p_,
                   int power_, double tol_)
       : h(h_), T(T_), Ns{Nx, Ny}, n_fields(n_fields_), rotated(rotated_), p(p_), power(power_), tol(tol_), cplx(ht_host != nullptr),
-        solver(h_->st, h_->gws, h_->ews, h_->tm), rot(h_->st, h_->tm) {
+        solver(h_->st, h_->gws, h_->ews, h_->tm), rot(h_->st, h_->tm, h_->gws, h_->ews) {
     static const bool analytic_on = [] { const char* e = std::getenv("XMCA_ANALYTIC"); return !(e && e[0] == '0'); }();
     analytic = cplx && analytic_on && Nx > T && (n_fields == 1 || Ny > T);
     if (cplx && !analytic) build_hilbert<TI>(h, ht_host, T, htb);
@@ -767,7 +767,7 @@ int xmca_rotate_loadings(xmca_handle* h, const double* L, int64_t N, int64_t n_l
   XMCA_CHECK(power >= 1, XMCA_ERR_INVALID, "rotate: `power` must be >= 1");
   XMCA_CHECK(n_left >= 0 && n_left <= N && max_iter >= 1, XMCA_ERR_INVALID, "rotate: bad n_left / max_iter");
   const bool cplx = is_complex != 0;
-  Rotator rot(h->st, h->tm);
+  Rotator rot(h->st, h->tm, h->gws, h->ews);
   rot.gamma = gamma;
   RotationDevice& d = h->rot;
   rot.alloc(d, N, n_left, p, cplx);
