@@ -38,6 +38,19 @@ def gold():
 @pytest.mark.parametrize("preprocess", ["host", "device"])
 @pytest.mark.parametrize("name,cplx,n_rot,power", CONFIGS)
 def test_config_matches_reference(gold, name, cplx, n_rot, power, preprocess):
+    _check_config(gold, name, cplx, n_rot, power, preprocess)
+
+
+def test_c3_at_full_size_matches_reference():
+    """configs[2] at FULL size - T = 5000 x (20 000, 15 000) float64, complexify=True, rotate(20, 4) - against the real
+    reference's output (oracle/make_config_goldens.py c3_full: 275 s of CPU; loadings stored at every 8th grid point, PCs at
+    every 5th time step): all 5000 singular values, the 20 leading loadings of both fields, R, Phi, norms, variance, PCs
+    and the Varimax iteration count."""
+    gold = np.load(os.path.join(GOLDEN_DIR, "config_c3_full.npz"))
+    _check_config(gold, "c3_full", True, 20, 4, "device")
+
+
+def _check_config(gold, name, cplx, n_rot, power, preprocess):
     g = {k[len(name) + 2:]: gold[k] for k in gold.files if k.startswith(name + "__")}
     fields = make_input(name)
     f32 = fields[0].dtype == np.float32
@@ -83,7 +96,7 @@ def test_config_matches_reference(gold, name, cplx, n_rot, power, preprocess):
     pcs = m.pcs(n_rot)
     for key in m._keys:
         assert _rel(m._norm[key], g["norm_" + key]) < t
-        al, _ = align_modes(pcs[key], g["pcs_" + key])
+        al, _ = align_modes(pcs[key][::int(g["pcs_stride"]) if "pcs_stride" in g else 1], g["pcs_" + key])
         assert _rel(al, g["pcs_" + key]) < (5e-3 if f32 else 1e-4)
     # ---- properties over ALL grid points (the goldens hold a subset for c5) ----
     # (two fields: sigma^2 = lambda(K K^H) - orthogonality of weak modes degrades like 5e-14 (sigma_1 / sigma_m)^2)

@@ -761,8 +761,53 @@ __device__ __forceinline__ int varimax_ns_wave16(const double* __restrict__ Gr, 
   return it < 100 ? it : -1;
 }
 
+// One 16 x 16 tile of T = X^H X (TSTEP) or of Y = X T (!TSTEP) with the KS k-steps unrolled: the accumulators then stay
+// in the MFMA's registers from the first to the last step (as a run-time loop the compiler moves all of them to VGPRs
+// and back every step and waits for each MFMA - 2.3x the time of the whole iteration).  (ar, ai) is the A operand at
+// a0 + s * sa, (br, bi) the B operand at b0 + s * sb; the last step's summation index is clamped and masked.
+template <bool CPLX, bool TSTEP, int KS>
+__device__ __forceinline__ void ns_tile_unrolled(const double* __restrict__ Ar, const double* __restrict__ Ai,
+                                                 const double* __restrict__ Br, const double* __restrict__ Bi, const int a0,
+                                                 const int sa, const int b0, const int sb, const int last_a, const int last_b,
+                                                 const double last_mask, d4_t& acc_r, d4_t& acc_i) {
+  double ar[KS], ai[KS], br[KS], bi[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int ia = s == KS - 1 ? last_a : a0 + s * sa, ib = s == KS - 1 ? last_b : b0 + s * sb;
+    ar[s] = Ar[ia];
+    br[s] = Br[ib];
+    if constexpr (CPLX) { ai[s] = Ai[ia]; bi[s] = Bi[ib]; }
+  }
+  __builtin_amdgcn_sched_barrier(0);   // every load is in flight before the first MFMA (otherwise: load, wait, MFMA, load, ...)
+  ar[KS - 1] *= last_mask;
+  if constexpr (CPLX) ai[KS - 1] *= last_mask;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    acc_r = Mfma<double>::mma(ar[s], br[s], acc_r);
+    if constexpr (CPLX) {
+      acc_r = Mfma<double>::mma(TSTEP ? ai[s] : -ai[s], bi[s], acc_r);   // T: conj(a) b;  Y: a b
+      acc_i = Mfma<double>::mma(ar[s], bi[s], acc_i);
+      acc_i = Mfma<double>::mma(TSTEP ? -ai[s] : ai[s], br[s], acc_i);
+    }
+  }
+}
+
+template <bool CPLX, bool TSTEP>
+__device__ __forceinline__ void ns_tile(const int ksteps, const double* __restrict__ Ar, const double* __restrict__ Ai,
+                                        const double* __restrict__ Br, const double* __restrict__ Bi, const int a0, const int sa,
+                                        const int b0, const int sb, const int last_a, const int last_b, const double last_mask,
+                                        d4_t& acc_r, d4_t& acc_i) {
+#define XMCA_NS_CASE(KS) case KS: ns_tile_unrolled<CPLX, TSTEP, KS>(Ar, Ai, Br, Bi, a0, sa, b0, sb, last_a, last_b, last_mask, acc_r, acc_i); break;
+  switch (ksteps) {   // 16 < p <= 64
+    XMCA_NS_CASE(5) XMCA_NS_CASE(6) XMCA_NS_CASE(7) XMCA_NS_CASE(8) XMCA_NS_CASE(9) XMCA_NS_CASE(10) XMCA_NS_CASE(11)
+    XMCA_NS_CASE(12) XMCA_NS_CASE(13) XMCA_NS_CASE(14) XMCA_NS_CASE(15) XMCA_NS_CASE(16)
+    default: break;
+  }
+#undef XMCA_NS_CASE
+}
+
 template <bool CPLX>
-__device__ void varimax_polar_step(double* __restrict__ sm, const double* __restrict__ part_r, const double* __restrict__ part_i,
+__device__ __forceinline__ void varimax_polar_step(double* __restrict__ sm, const double* __restrict__ part_r, const double* __restrict__ part_i,
                                    int nwg, int p, const double* __restrict__ A0r, const double* __restrict__ A0i,
                                    double* __restrict__ Rr, double* __restrict__ Ri, double* __restrict__ cvec,
                                    double* __restrict__ state, double tol) {
@@ -863,7 +908,6 @@ __device__ void varimax_polar_step(double* __restrict__ sm, const double* __rest
   double* Ci = Xi;
   double* Nr = Yr;   // next iterate
   double* Ni = Yi;
-  const int j0 = tid / p, k0 = tid % p;
   int* nsflag = reinterpret_cast<int*>(scr + 1008);    // [0..1]: "not converged" by parity, [2]: NaN seen, [3]: wave16 result
   if (tid < 3) nsflag[tid] = 0;
   __syncthreads();
@@ -879,55 +923,62 @@ __device__ void varimax_polar_step(double* __restrict__ sm, const double* __rest
     ok = it >= 0;
     if (!ok) it = 100;
   }
+  // p > 16: the two products of an iteration as 16 x 16 MFMA tiles (v_mfma_f64_16x16x4_f64), the PT x PT output tiles
+  // dealt round-robin to the four waves; operands straight from LDS (X and T at pitch p).  Rows / columns beyond p are
+  // read from a clamped address - an operand row (column) only reaches the same row (column) of the product, which is
+  // not stored - and the summation index beyond p (last step only) is masked with a factor 0: no branch around any load.
+  //   T = X^H X :  a = X[k][16 ti + i], b = X[k][16 tj + j]:   Tr = ar br + ai bi,  Ti = ar bi - ai br
+  //   Y = X T   :  a = X[16 ti + i][k], b = T[k][16 tj + j]:   Yr = ar br - ai bi,  Yi = ar bi + ai br
+  const int lane = tid & 63, l15 = lane & 15, l4 = lane >> 4, wv = tid >> 6;
+  const int PT = (p + 15) >> 4, ksteps = (p + 3) >> 2;
+  const int klast = min(4 * (ksteps - 1) + l4, p - 1);                    // summation index of the last step, clamped ...
+  const double kmask = 4 * (ksteps - 1) + l4 < p ? 1.0 : 0.0;             // ... and masked
   for (; p > 16 && it < 100; ++it) {
-    for (int e = tid; e < pp; e += 256) {
-      const int j = (e == tid) ? j0 : e / p, k = (e == tid) ? k0 : e % p;
-      double tr = 0.0, ti = 0.0;
-      const double* cj = Cr + j;
-      const double* ck = Cr + k;
-      const double* dj = Ci + j;
-      const double* dk = Ci + k;
-#pragma unroll 5
-      for (int m = 0; m < p; ++m) {
-        const double ar = cj[m * p], br = ck[m * p];
-        tr += ar * br;
-        if constexpr (CPLX) {
-          const double ai = dj[m * p], bi = dk[m * p];
-          tr += ai * bi;                 // conj(a) b
-          ti += ar * bi - ai * br;
+    if (it == 1) ROT_STAMP(8);
+    for (int t = wv; t < PT * PT; t += 4) {
+      const int ia = 16 * (t / PT) + l15, jb = 16 * (t % PT) + l15, ca = min(ia, p - 1), cb = min(jb, p - 1);
+      d4_t tr = {0, 0, 0, 0}, ti = {0, 0, 0, 0};
+      ns_tile<CPLX, true>(ksteps, Cr, Ci, Cr, Ci, l4 * p + ca, 4 * p, l4 * p + cb, 4 * p, klast * p + ca, klast * p + cb, kmask, tr, ti);
+      if (it == 1) ROT_STAMP(14);
+      bool open = false, nan = false;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * (t / PT) + l4 + 4 * r;
+        if (row < p && jb < p) {
+          Tr[row * p + jb] = tr[r];
+          if constexpr (CPLX) Ti[row * p + jb] = ti[r];
+          const double err = fmax(fabs(tr[r] - (row == jb ? 1.0 : 0.0)), fabs(ti[r]));
+          open |= !(err < 1e-14);
+          nan |= !(tr[r] == tr[r]) || !(ti[r] == ti[r]) || err == HUGE_VAL;
         }
       }
-      Tr[e] = tr;
-      if constexpr (CPLX) Ti[e] = ti;
-      const double err = fmax(fabs(tr - (j == k ? 1.0 : 0.0)), fabs(ti));
-      if (!(err < 1e-14)) nsflag[it & 1] = 1;
-      if (!(tr == tr) || !(ti == ti) || err == HUGE_VAL) nsflag[2] = 1;
+      if (open) nsflag[it & 1] = 1;
+      if (nan) nsflag[2] = 1;
     }
     if (tid == 0) nsflag[(it + 1) & 1] = 0;   // next iteration's flag (its last reader passed the previous barrier)
+    if (it == 1) ROT_STAMP(9);
     __syncthreads();
+    if (it == 1) ROT_STAMP(10);
     if (nsflag[2]) break;                       // NaN / inf
     if (!nsflag[it & 1]) { ok = true; break; }
-    for (int e = tid; e < pp; e += 256) {
-      const int j = (e == tid) ? j0 : e / p, k = (e == tid) ? k0 : e % p;
-      double yr = 0.0, yi = 0.0;
-      const double* xj = Cr + j * p;
-      const double* yj = Ci + j * p;
-      const double* tk = Tr + k;
-      const double* uk = Ti + k;
-#pragma unroll 5
-      for (int m = 0; m < p; ++m) {
-        const double xr = xj[m], t_r = tk[m * p];
-        yr += xr * t_r;
-        if constexpr (CPLX) {
-          const double xi = yj[m], t_i = uk[m * p];
-          yr -= xi * t_i;
-          yi += xr * t_i + xi * t_r;
+    if (it == 1) ROT_STAMP(11);
+    for (int t = wv; t < PT * PT; t += 4) {
+      const int ia = 16 * (t / PT) + l15, jb = 16 * (t % PT) + l15, ca = min(ia, p - 1), cb = min(jb, p - 1);
+      d4_t yr = {0, 0, 0, 0}, yi = {0, 0, 0, 0};
+      ns_tile<CPLX, false>(ksteps, Cr, Ci, Tr, Ti, ca * p + l4, 4, l4 * p + cb, 4 * p, ca * p + klast, klast * p + cb, kmask, yr, yi);
+      if (it == 1) ROT_STAMP(15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * (t / PT) + l4 + 4 * r;
+        if (row < p && jb < p) {
+          Nr[row * p + jb] = 1.5 * Cr[row * p + jb] - 0.5 * yr[r];
+          if constexpr (CPLX) Ni[row * p + jb] = 1.5 * Ci[row * p + jb] - 0.5 * yi[r];
         }
       }
-      Nr[e] = 1.5 * Cr[e] - 0.5 * yr;
-      if constexpr (CPLX) Ni[e] = 1.5 * Ci[e] - 0.5 * yi;
     }
+    if (it == 1) ROT_STAMP(12);
     __syncthreads();
+    if (it == 1) ROT_STAMP(13);
     { double* t = Cr; Cr = Nr; Nr = t; }
     { double* t = Ci; Ci = Ni; Ni = t; }
   }
