@@ -110,6 +110,7 @@ struct SolveResult {
   CPlanes Vt[2];                       // n_vec x N_k planes (row m = mode m)
   int64_t ldv[2] = {0, 0};
   bool cplx = false;
+  bool weak_refined = false;          // the route refined its weak modes itself (Solver::refine_weak_block)
   EvdInfo evd_info[3];
 };
 
@@ -178,8 +179,9 @@ class Solver {
 
   // n_vec < 0: all modes
   void solve(const FieldData<TI>* fields, int n_fields, bool cplx, int n_vec_req, SolveResult& out) {
+    out.weak_refined = false;            // (the caller may hand in the result object of an earlier solve)
     solve_core(fields, n_fields, cplx, n_vec_req, out);
-    if (n_fields == 2) refine_by_deflation(fields, cplx, out);
+    if (n_fields == 2 && !out.weak_refined) refine_by_deflation(fields, cplx, out);
   }
 
   // -------------------------------------------------------------------------------------------------------------
@@ -531,6 +533,9 @@ class Solver {
     cgemm<double>(st, gws, Tha.r(), Tha.i(cplx), T, true, false, Gb.r(), Gb.i(cplx), T, true, false, Thl.r(), Thl.i(cplx), T, m, T, T, 1.0,
                   nullptr, nullptr, false);
     XMCA_HIP(hipStreamSynchronize(st));
+    // (the weak modes of this route are refined from the deflated FIELDS, Solver::refine_by_deflation: on spectra graded over
+    //  10 decades the weak block of H - refine_weak_block, enough for the analytic route - stops at ~1e-7 sigma_1 here, because
+    //  the eigen-decomposition of G_a itself carries an absolute error of eps lambda_a1)
     back_project(B, cplx, Tha.r(), Tha.i(cplx), m, out.Vt[1]);
     back_project(A, cplx, Thl.r(), Thl.i(cplx), m, out.Vt[0]);
     tm.end();
@@ -643,7 +648,8 @@ class Solver {
   //     H_w[i][j] = p_i^H H p_j = El_i Er_j^H / dof^2        (norm sigma_{ns+1}^2, error eps sigma_1 sigma_w)
   // and its eigen-decomposition H_w = Z^H L Z - a nearly diagonal matrix, two or three Jacobi sweeps - replaces sigma and
   // rotates the weak rows: Er_w <- Z Er_w, El_w <- Z El_w.  Up to three levels, as in refine_by_deflation; same switch.
-  void refine_weak_block(CPlanes& Er, CPlanes& El, int nv, int m, double dof, SolveResult& out) {
+  void refine_weak_block(CPlanes& Er, CPlanes& El, int nv, int m, double dof, SolveResult& out, bool cplx = true) {
+    if constexpr (std::is_same<TI, float>::value) return;        // float32 fields: sigma is resolved to 6e-8 sigma_1 at best
     static const double thr = [] { const char* e = std::getenv("XMCA_DEFLATE_BELOW"); return e ? std::atof(e) : 1e-3; }();   // 0: off
     if (thr <= 0.0 || nv <= 1 || !(out.sigma[0] > 0.0)) return;
     int done = 0;
@@ -657,29 +663,30 @@ class Solver {
       const int nw = nv - ns;
       tm.begin("refine_weak");
       CPlanes Hw, Z, Tmp;
-      Hw.ensure((size_t)nw * nw, true);
-      Z.ensure((size_t)nw * nw, true);
-      Tmp.ensure((size_t)nw * m, true);
+      Hw.ensure((size_t)nw * nw, cplx);
+      Z.ensure((size_t)nw * nw, cplx);
+      Tmp.ensure((size_t)nw * m, cplx);
       double* er_r = Er.r() + (int64_t)ns * m;
-      double* er_i = Er.im.get() + (int64_t)ns * m;
+      double* er_i = cplx ? Er.im.get() + (int64_t)ns * m : nullptr;
       double* el_r = El.r() + (int64_t)ns * m;
-      double* el_i = El.im.get() + (int64_t)ns * m;
-      cgemm<double>(st, gws, el_r, el_i, m, true, false, er_r, er_i, m, false, true, Hw.r(), Hw.im.get(), nw, nw, nw, m,
+      double* el_i = cplx ? El.im.get() + (int64_t)ns * m : nullptr;
+      cgemm<double>(st, gws, el_r, el_i, m, true, false, er_r, er_i, m, false, true, Hw.r(), Hw.i(cplx), nw, nw, nw, m,
                     1.0 / (dof * dof), nullptr, nullptr, true);
       std::vector<double> lam;
-      hermitian_evd(st, ews, Hw.r(), Hw.im.get(), nw, nw, lam, nullptr, Z.r(), Z.im.get(), nw, &out.evd_info[1]);
+      hermitian_evd(st, ews, Hw.r(), Hw.i(cplx), nw, nw, lam, nullptr, Z.r(), Z.i(cplx), nw, &out.evd_info[1]);
       for (double* base : {er_r, el_r}) {
         double* im = base == er_r ? er_i : el_i;
-        cgemm<double>(st, gws, Z.r(), Z.im.get(), nw, true, false, base, im, m, true, false, Tmp.r(), Tmp.im.get(), m, nw, m, nw, 1.0,
+        cgemm<double>(st, gws, Z.r(), Z.i(cplx), nw, true, false, base, im, m, true, false, Tmp.r(), Tmp.i(cplx), m, nw, m, nw, 1.0,
                       nullptr, nullptr, false);
         XMCA_HIP(hipMemcpyAsync(base, Tmp.r(), sizeof(double) * (size_t)nw * m, hipMemcpyDeviceToDevice, st));
-        XMCA_HIP(hipMemcpyAsync(im, Tmp.im.get(), sizeof(double) * (size_t)nw * m, hipMemcpyDeviceToDevice, st));
+        if (cplx) XMCA_HIP(hipMemcpyAsync(im, Tmp.im.get(), sizeof(double) * (size_t)nw * m, hipMemcpyDeviceToDevice, st));
       }
       XMCA_HIP(hipStreamSynchronize(st));
       tm.end();
       for (int j = 0; j < nw; ++j) out.sigma[ns + j] = std::sqrt(std::max(lam[j], 0.0));
       done = ns;
     }
+    out.weak_refined = true;
   }
 
   static bool analytic_applicable(const FieldData<TI>* fields, int n_fields) {
@@ -696,6 +703,7 @@ class Solver {
     analytic_basis(T, an);
     const int m = an.m;
     out.cplx = true;
+    out.weak_refined = false;
     out.rank = T;                                   // min(T, N) as the reference reports it (array.py:597)
     const int n_vec = n_vec_req < 0 ? T : std::min(n_vec_req, T);
     const int nv = std::min(n_vec, m);              // modes that can be non-null
