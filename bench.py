@@ -94,7 +94,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rule-n", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
-    ap.add_argument("--rule-n-runs", type=int, default=3, help="timed rule_n surrogates per GPU (C4 configuration)")
+    ap.add_argument("--rule-n-runs", type=int, default=4, help="timed rule_n surrogates per GPU (C4 configuration)")
     ap.add_argument("--rule-n-rotated", action="store_true",
                     help="also time the ROTATED C4 variant (n_rot=20, power=4) and report its dropped runs")
     args = ap.parse_args()
@@ -234,7 +234,7 @@ def main():
     if not args.no_rule_n:
         Tn, Nxn, Nyn = 5000, 20000, 15000               # BASELINE.json configs[3]: rule_n on the synthetic MCA config
         model = rule_n_model(MCA, h, Tn, Nxn, Nyn)
-        model.rule_n(world, seed=7)                   # one untimed surrogate per rank (workspaces, tile maps)
+        model.rule_n(2 * world, seed=7)               # two untimed surrogates per rank (workspaces of both lanes, tile maps)
         n_runs = args.rule_n_runs * world
         barrier()
         t0 = time.perf_counter()
@@ -246,7 +246,8 @@ def main():
             td.all_reduce(tt, op=td.ReduceOp.MAX)
             dt = float(tt.item())
         extra["rule_n"] = {"config": "C4: MCA T=%d x (%d, %d) f64 surrogates, complexify=True, unrotated; %d runs per GPU, "
-                                     "run-sharded, one all_gather (%s)" % (Tn, Nxn, Nyn, args.rule_n_runs, backend if world > 1 else "single rank"),
+                                     "run-sharded, one all_gather (%s); two surrogates in flight per GPU (XMCA_RULE_N_LANES)" % (
+                                         Tn, Nxn, Nyn, args.rule_n_runs, backend if world > 1 else "single rank"),
                            "runs": n_runs, "surrogates_per_s": n_runs / dt, "shape": list(sp.shape),
                            "spectrum_sum_check": float(abs(sp.sum(axis=0) / model._get_variance().sum() - 1).max())}
         if args.rule_n_rotated:

@@ -195,3 +195,36 @@ def test_bench_py_launches_its_own_ranks():
     bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4", "--steps", "1"],
                          env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=REPO, capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr
+
+
+def test_rule_n_spectra_do_not_depend_on_the_number_of_lanes():
+    """xmca_rule_n keeps several surrogates in flight (one stream + workspaces + host thread per lane, xmca_hip.cpp
+    rule_n_impl); the generator is keyed by (seed, run, side), so 1, 2, 3 and 5 lanes must give the same bits - unrotated,
+    rotated with dropped runs, and with the device memory pool switched off."""
+    import subprocess
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from xmca_amd import _hip; h = _hip.Handle(0);"
+            "a, ka = h.rule_n(60, 300, 200, 2, True, False, 0, 1, 1e-8, 0, 7, 5, np.float64, 60);"
+            "b, kb = h.rule_n(150, 400, 300, 2, True, True, 30, 4, 1e-8, 0, 6, 99, np.float64, 30);"
+            "c, kc = h.rule_n(48, 120, 0, 1, False, True, 4, 1, 1e-8, 2, 9, 3, np.float32, 4);"
+            "np.savez(sys.argv[1], a=a, ka=ka, b=b, kb=kb, c=c, kc=kc)" % REPO)
+    import tempfile
+    outs = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for lanes, pool in [("1", "1"), ("2", "1"), ("3", "1"), ("5", "0")]:
+            dst = os.path.join(tmp, "l%s.npz" % lanes)
+            env = dict(os.environ, XMCA_RULE_N_LANES=lanes, XMCA_POOL=pool)
+            r = subprocess.run([sys.executable, "-c", code, dst], env=env, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs.append(dict(np.load(dst)))
+    assert 0 in outs[0]["kb"] and 1 in outs[0]["kb"]                 # the rotated case drops some runs and keeps others
+    for o in outs[1:]:
+        for k in outs[0]:
+            assert np.array_equal(o[k], outs[0][k]), k
+
+
+def test_an_error_in_a_lane_is_reported(hip):
+    """n_out that does not match the rank is rejected inside every lane (first error wins, the others are joined)."""
+    with pytest.raises(Exception, match="n_out"):
+        hip.rule_n(40, 24, 18, 2, False, False, 0, 1, 1e-8, 0, 6, 1, np.float64, 17)
+    sp, kept = hip.rule_n(40, 24, 18, 2, False, False, 0, 1, 1e-8, 0, 6, 1, np.float64, 18)      # the handle is still usable
+    assert sp.shape == (6, 18) and kept.sum() == 6

@@ -7,6 +7,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <map>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -35,29 +37,121 @@ struct Error : std::runtime_error {
     if (!(cond)) throw ::xmca::Error((code), (msg));       \
   } while (0)
 
-// Owning device buffer (hipMalloc).  Grows on demand, never shrinks.
+// Device memory pool of one handle (one stream).  A solve takes and returns dozens of temporaries; hipMalloc maps pages
+// (~0.1-1 ms for the sizes here) and hipFree waits for the WHOLE device, which also serialises handles that work side by
+// side on different streams (the surrogate lanes of rule_n).  Blocks given back are kept and handed out again by size.
+// Re-use is safe without events because a pool serves exactly one stream: whatever still reads a returned block was
+// enqueued on that stream before whatever writes it next.  The calling thread names its pool with a PoolScope (API entry
+// points, lane threads); a DevBuf remembers the pool it came from and returns there from any thread.
+// Blocks above `keep_limit` in total are freed straight away; XMCA_POOL=0 switches pooling off.
+struct DevPool {
+  std::mutex mu;
+  std::multimap<size_t, void*> blocks;     // capacity in bytes -> free block
+  size_t held = 0;
+  size_t keep_limit = (size_t)96 << 30;
+  static bool enabled() {
+    static const bool on = [] { const char* e = std::getenv("XMCA_POOL"); return !(e && e[0] == '0'); }();
+    return on;
+  }
+  void* take(size_t bytes, size_t* cap) {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      auto it = blocks.lower_bound(bytes);
+      if (it != blocks.end() && it->first <= bytes + bytes / 4 + ((size_t)1 << 20)) {
+        void* p = it->second;
+        *cap = it->first;
+        held -= it->first;
+        blocks.erase(it);
+        return p;
+      }
+    }
+    void* p = nullptr;
+    const size_t want = (bytes + 255) & ~(size_t)255;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {               // out of memory: give the kept blocks back and try once more
+      (void)hipGetLastError();
+      trim();
+      e = hipMalloc(&p, want);
+    }
+    if (e != hipSuccess)
+      throw Error(XMCA_ERR_HIP, std::string("hipMalloc of ") + std::to_string(want) + " bytes: " + hipGetErrorString(e));
+    *cap = want;
+    return p;
+  }
+  void give(void* p, size_t cap) {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      if (held + cap <= keep_limit) {
+        blocks.emplace(cap, p);
+        held += cap;
+        return;
+      }
+    }
+    (void)hipFree(p);
+  }
+  void trim() {
+    std::lock_guard<std::mutex> g(mu);
+    for (auto& b : blocks) (void)hipFree(b.second);
+    blocks.clear();
+    held = 0;
+  }
+  ~DevPool() { trim(); }
+};
+
+inline DevPool*& current_pool() {
+  thread_local DevPool* p = nullptr;
+  return p;
+}
+struct PoolScope {
+  DevPool* prev;
+  explicit PoolScope(DevPool* p) : prev(current_pool()) { current_pool() = DevPool::enabled() ? p : nullptr; }
+  ~PoolScope() { current_pool() = prev; }
+  PoolScope(const PoolScope&) = delete;
+  PoolScope& operator=(const PoolScope&) = delete;
+};
+
+// Owning device buffer.  Grows on demand, never shrinks; from the calling thread's pool when it has one, else hipMalloc.
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
-  size_t cap = 0;  // elements
+  size_t cap = 0;            // elements
+  size_t cap_bytes = 0;      // size of the underlying block
+  DevPool* owner = nullptr;
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
-  DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+  DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap), cap_bytes(o.cap_bytes), owner(o.owner) { o.p = nullptr; o.cap = 0; o.cap_bytes = 0; o.owner = nullptr; }
   DevBuf& operator=(DevBuf&& o) noexcept {
-    if (this != &o) { release(); p = o.p; cap = o.cap; o.p = nullptr; o.cap = 0; }
+    if (this != &o) {
+      release();
+      p = o.p; cap = o.cap; cap_bytes = o.cap_bytes; owner = o.owner;
+      o.p = nullptr; o.cap = 0; o.cap_bytes = 0; o.owner = nullptr;
+    }
     return *this;
   }
   ~DevBuf() { release(); }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) {
+      if (owner) owner->give(p, cap_bytes);
+      else (void)hipFree(p);
+    }
     p = nullptr;
     cap = 0;
+    cap_bytes = 0;
+    owner = nullptr;
   }
   T* ensure(size_t n) {
     if (n > cap) {
       release();
-      XMCA_HIP(hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T)));
+      DevPool* pool = current_pool();
+      if (pool) {
+        p = static_cast<T*>(pool->take(n * sizeof(T), &cap_bytes));
+        owner = pool;
+        n = cap_bytes / sizeof(T);
+      } else {
+        XMCA_HIP(hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T)));
+        cap_bytes = n * sizeof(T);
+      }
       cap = n;
     }
     return p;

@@ -1,4 +1,6 @@
 // C ABI of libxmca_hip.so (see include/xmca_hip.h).  Compiled for gfx950 only.
+#include <thread>
+#include <exception>
 #include "../../include/xmca_hip.h"
 
 #include <cstring>
@@ -10,8 +12,10 @@
 using namespace xmca;
 
 struct xmca_handle {
+  ::xmca::DevPool pool;                   // first member: destroyed after every buffer below has gone back to it
   int device = 0;
   hipStream_t st = nullptr;
+  std::vector<xmca_handle*> lanes;        // extra streams + workspaces for the concurrent surrogate lanes of rule_n
   std::string err;
   GemmWorkspace gws;
   EvdWorkspace ews;
@@ -40,6 +44,7 @@ struct xmca_handle {
 #define API_BEGIN(h)                                                   \
   if (!(h)) return XMCA_ERR_INVALID;                                   \
   try {                                                                \
+    ::xmca::PoolScope _pool_scope(&(h)->pool);                         \
     XMCA_HIP(hipSetDevice((h)->device));
 #define API_END(h)                                                     \
   }                                                                    \
@@ -81,6 +86,8 @@ int xmca_create(int device, xmca_handle** out) {
 
 void xmca_destroy(xmca_handle* h) {
   if (!h) return;
+  for (xmca_handle* lane : h->lanes) xmca_destroy(lane);
+  h->lanes.clear();
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->st);
   try { h->tm.reset(); } catch (...) {}
@@ -473,15 +480,22 @@ struct ReplicateRunner {
   }
 };
 
+// Surrogates are independent: `lanes` of them are in flight at a time, each on its own stream with its own workspaces
+// and host thread (the solver synchronises its stream now and then, so a lane needs a thread of its own).  A round of
+// the eigensolver leaves the chip partly idle - its tile-solve chain and the tail of its updates - and a
+// second surrogate's kernels fill that: measured at C4 as two PROCESSES sharing the GPU +34 % surrogates/s
+// (profiles/r02_bench_shared_gpu_2ranks.json), now inside one process.  Lane j takes the runs j, j + lanes, ...; the
+// generator is keyed by (seed, run, side), so the spectra do not depend on the number of lanes.  XMCA_RULE_N_LANES
+// (default: 2 for eigenproblems of 2000 and more, 4 below; 1 = the plain loop).
 template <typename TI>
-void rule_n_impl(xmca_handle* h, int64_t T, int64_t Nx, int64_t Ny, int n_fields, const double* ht_host, int rotated, int p,
-                 int power, double tol, int64_t run_begin, int64_t run_end, uint64_t seed, double* spectra, int* kept,
+void rule_n_lane(xmca_handle* h, int64_t T, int64_t Nx, int64_t Ny, int n_fields, const double* ht_host, int rotated, int p, int power,
+                 double tol, int64_t run_begin, int64_t run_end, int64_t first, int64_t stride, uint64_t seed, double* spectra, int* kept,
                  int64_t n_out) {
   FieldData<TI> f[2];
   const int64_t Ns[2] = {Nx, Ny};
   ReplicateRunner<TI> runner(h, T, Nx, Ny, n_fields, ht_host, rotated, p, power, tol);
   XMCA_CHECK(n_out == (rotated ? (int64_t)p : runner.rank()), XMCA_ERR_INVALID, "rule_n: n_out must be rank (unrotated) or p (rotated)");
-  for (int64_t run = run_begin; run < run_end; ++run) {
+  for (int64_t run = run_begin + first; run < run_end; run += stride) {
     h->tm.begin("surrogate");
     for (int s = 0; s < n_fields; ++s) {
       f[s].T = T; f[s].N = Ns[s]; f[s].has_im = false;
@@ -495,6 +509,61 @@ void rule_n_impl(xmca_handle* h, int64_t T, int64_t Nx, int64_t Ny, int n_fields
     h->tm.end();
     kept[run - run_begin] = runner.run(f, spectra + (run - run_begin) * n_out, n_out);
   }
+  XMCA_HIP(hipStreamSynchronize(h->st));
+}
+
+template <typename TI>
+void rule_n_impl(xmca_handle* h, int64_t T, int64_t Nx, int64_t Ny, int n_fields, const double* ht_host, int rotated, int p,
+                 int power, double tol, int64_t run_begin, int64_t run_end, uint64_t seed, double* spectra, int* kept,
+                 int64_t n_out) {
+  // measured on MI355X (scripts/rule_n_bench.py, surrogates/s with 1 / 2 / 3 / 4 lanes): C4 8.0 / 10.6 / 10.4 / 10.4,
+  // C2-shaped EOF 25.8 / 32.9 / 33.1 / 32.3, C1-shaped (eigenproblems of 675) 109 / 191 / 265 / 337
+  static const int lanes_env = [] { const char* e = std::getenv("XMCA_RULE_N_LANES"); return e ? std::max(1, std::min(8, std::atoi(e))) : 0; }();
+  const int64_t eig_n = std::min(T, n_fields == 2 ? std::min(Nx, Ny) : Nx);
+  const int lanes_wanted = lanes_env ? lanes_env : (eig_n >= 2000 ? 2 : 4);
+  const int lanes = (int)std::min<int64_t>(lanes_wanted, std::max<int64_t>(run_end - run_begin, 1));
+  if (lanes <= 1) {
+    rule_n_lane<TI>(h, T, Nx, Ny, n_fields, ht_host, rotated, p, power, tol, run_begin, run_end, 0, 1, seed, spectra, kept, n_out);
+    return;
+  }
+  while ((int)h->lanes.size() < lanes - 1) {
+    xmca_handle* lane = nullptr;
+    XMCA_CHECK(xmca_create(h->device, &lane) == XMCA_OK, XMCA_ERR_HIP, "rule_n: cannot create a lane (stream)");
+    h->lanes.push_back(lane);
+  }
+  std::vector<std::exception_ptr> errs((size_t)lanes);
+  std::vector<std::thread> threads;
+  auto body = [&](int j) {
+    xmca_handle* lh = j == 0 ? h : h->lanes[(size_t)j - 1];
+    try {
+      ::xmca::PoolScope scope(&lh->pool);
+      XMCA_HIP(hipSetDevice(h->device));
+      lh->tm.enabled = h->tm.enabled;
+      rule_n_lane<TI>(lh, T, Nx, Ny, n_fields, ht_host, rotated, p, power, tol, run_begin, run_end, j, lanes, seed, spectra, kept, n_out);
+    } catch (...) {
+      errs[(size_t)j] = std::current_exception();
+      (void)hipStreamSynchronize(lh->st);
+    }
+  };
+  for (int j = 1; j < lanes; ++j) threads.emplace_back(body, j);
+  body(0);
+  for (auto& t : threads) t.join();
+  // stage times and eigensolver round counters of the lanes are added to the caller's (they overlap in wall-clock time)
+  for (xmca_handle* lane : h->lanes) {
+    lane->tm.collect();
+    for (const auto& name : lane->tm.order) {
+      if (!h->tm.ms.count(name)) h->tm.order.push_back(name);
+      h->tm.ms[name] += lane->tm.ms[name];
+    }
+    lane->tm.ms.clear();
+    lane->tm.order.clear();
+    h->ews.w64.round_ms += lane->ews.w64.round_ms; h->ews.w64.round_launches += lane->ews.w64.round_launches;
+    h->ews.w32.round_ms += lane->ews.w32.round_ms; h->ews.w32.round_launches += lane->ews.w32.round_launches;
+    lane->ews.w64.round_ms = lane->ews.w32.round_ms = 0.0;
+    lane->ews.w64.round_launches = lane->ews.w32.round_launches = 0;
+  }
+  for (auto& e : errs)
+    if (e) std::rethrow_exception(e);
 }
 
 // ---- bootstrapping: working copies on the device -----------------------------------------------------------------
