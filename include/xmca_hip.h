@@ -41,7 +41,7 @@ typedef struct xmca_handle xmca_handle;
 /* library / device management ------------------------------------------------------------------------- */
 const char* xmca_version(void);
 /* Number of this header's ABI (XMCA_ABI_VERSION): the binding refuses a library built from another revision. */
-#define XMCA_ABI_VERSION 3
+#define XMCA_ABI_VERSION 4
 int xmca_abi_version(void);
 int xmca_device_count(void);
 int xmca_create(int device, xmca_handle** out);
@@ -122,6 +122,13 @@ int xmca_get_field(xmca_handle* h, int side, void* out);
 int xmca_bootstrap_begin(xmca_handle* h, int n_fields);
 int xmca_bootstrap_run(xmca_handle* h, const double* hilbert_col, const int64_t* idx_left, const int64_t* idx_right, int rotated,
                        int p, int power, double tol, double* spectrum_out, int* kept_out, int64_t n_out);
+/* All replicates of one bootstrap in one call.  idx_left / idx_right: n_runs x T row indices INTO THE FIELDS AS THEY WERE AT
+ * xmca_bootstrap_begin - the caller composes the reference's cumulative resampling, c_r = c_{r-1}[idx_r] (idx_r drawn exactly
+ * as tools/array.py:91-138 does) - or NULL for a side that is not resampled.  The replicates are then independent on the
+ * device and several are kept in flight (lanes, as in xmca_rule_n).  spectra_out: n_runs x n_out, kept_out: n_runs.
+ * Does not touch the cumulative state of xmca_bootstrap_run. */
+int xmca_bootstrap_runs(xmca_handle* h, const double* hilbert_col, const int64_t* idx_left, const int64_t* idx_right, int64_t n_runs,
+                        int rotated, int p, int power, double tol, double* spectra_out, int* kept_out, int64_t n_out);
 int xmca_is_complex(xmca_handle* h);
 /* Diagnostics of the last solve: for each of the up to three eigen-decompositions (left Gram, right Gram, kernel):
  * info[3*i + 0] = outer sweeps, info[3*i + 1] = tile size, info[3*i + 2] = pair slots (i = 0..2), then
@@ -163,6 +170,12 @@ int xmca_surrogate(xmca_handle* h, int64_t n, uint64_t seed, uint32_t run, uint3
  * (their number, in the ms array). */
 int xmca_get_timings(xmca_handle* h, char* names, int names_len, double* ms, int max_n);
 int xmca_reset_timings(xmca_handle* h);
+
+/* Device memory kept by the handle.  The solver's temporaries come from a per-handle pool (hipFree waits for the whole
+ * device): blocks are kept after a call, up to XMCA_POOL_LIMIT_GB (default 32) in total.
+ * xmca_pool_bytes reports what is held right now (lanes of rule_n included), xmca_trim_pool gives it back to the driver. */
+int xmca_pool_bytes(xmca_handle* h, int64_t* held_bytes);
+int xmca_trim_pool(xmca_handle* h);
 
 /* Kernel-level entry points used by the parity tests and the roofline leg of bench.py ------------------- */
 /* C (M x N, float64, host) = alpha * op(A) op(B);  a_kfast: A(m,k) = A[m*lda + k] else A[k*lda + m];

@@ -604,3 +604,23 @@ def test_model_identity_is_not_its_address():
         assert not b._owns_device_fields(dev)
         assert dev.fields_owner is key
         del b
+
+
+def test_device_memory_pool_is_reported_and_trimmed(hip):
+    """The solver's temporaries stay with the handle for re-use (csrc/common.h DevPool); `pool_bytes` reports them,
+    `trim_pool` returns them to the driver, and results do not depend on what the pool holds."""
+    from golden_inputs import make_input
+    from xmca_amd import _hip
+    h = _hip.Handle(0)
+    fields = make_input("wide_both")
+    a = MCA(*fields, handle=h)
+    a.solve(complexify=True)
+    s1 = a._singular_values.copy()
+    held = h.pool_bytes()
+    assert held > 0
+    h.trim_pool()
+    assert h.pool_bytes() == 0
+    b = MCA(*fields, handle=h)
+    b.solve(complexify=True)
+    assert np.array_equal(b._singular_values, s1)
+    assert h.pool_bytes() > 0

@@ -43,6 +43,7 @@ SIGNATURES = {
     "xmca_get_field": (_c_int, [_vp, _c_int, _vp]),
     "xmca_bootstrap_begin": (_c_int, [_vp, _c_int]),
     "xmca_bootstrap_run": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_dbl, _vp, ctypes.POINTER(_c_int), _c_i64]),
+    "xmca_bootstrap_runs": (_c_int, [_vp, _vp, _vp, _vp, _c_i64, _c_int, _c_int, _c_int, _c_dbl, _vp, _vp, _c_i64]),
     "xmca_correlate": (_c_int, [_vp, _c_int, _vp, _c_i64, _c_i64, _vp]),
     "xmca_project": (_c_int, [_vp, _c_int, _vp, _c_i64, _c_i64, _c_int, _vp, ctypes.POINTER(_c_int)]),
     "xmca_is_complex": (_c_int, [_vp]),
@@ -54,6 +55,8 @@ SIGNATURES = {
     "xmca_surrogate": (_c_int, [_vp, _c_i64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _vp]),
     "xmca_get_timings": (_c_int, [_vp, ctypes.c_char_p, _c_int, _vp, _c_int]),
     "xmca_reset_timings": (_c_int, [_vp]),
+    "xmca_pool_bytes": (_c_int, [_vp, ctypes.POINTER(ctypes.c_int64)]),
+    "xmca_trim_pool": (_c_int, [_vp]),
     "xmca_gemm": (_c_int, [_vp, _vp, _c_i64, _c_int, _vp, _c_i64, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_dbl,
                            _c_int, _c_int, _c_int]),
     "xmca_eigh": (_c_int, [_vp, _vp, _c_int, _c_int, _vp, _vp, _vp]),
@@ -69,7 +72,7 @@ def library_path():
     return _build.LIB
 
 
-ABI_VERSION = 3          # bumped whenever a signature of include/xmca_hip.h changes; checked against xmca_abi_version()
+ABI_VERSION = 4          # bumped whenever a signature of include/xmca_hip.h changes; checked against xmca_abi_version()
 
 
 def load_library():
@@ -323,6 +326,18 @@ class Handle:
                                                  _ptr(out), ctypes.byref(kept), n_out))
         return out, bool(kept.value)
 
+    def bootstrap_runs(self, T, complexify, idx_left, idx_right, n_runs, rotated, p, power, tol, n_out):
+        """All replicates in one call (several in flight on the device).  idx_*: (n_runs, T) COMPOSED row indices into the
+        fields as they were at `bootstrap_begin`, or None.  Returns (spectra[n_runs, n_out], kept[n_runs])."""
+        ht = hilbert_imag_column(T) if complexify else None
+        il = None if idx_left is None else np.ascontiguousarray(idx_left, dtype=np.int64).reshape(n_runs, T)
+        ir = None if idx_right is None else np.ascontiguousarray(idx_right, dtype=np.int64).reshape(n_runs, T)
+        out = np.zeros((n_runs, n_out), dtype=np.float64)
+        kept = np.zeros(n_runs, dtype=np.int32)
+        self._check(self._lib.xmca_bootstrap_runs(self._h, _ptr(ht), _ptr(il), _ptr(ir), n_runs, int(rotated), int(p), int(power),
+                                                  float(tol), _ptr(out), _ptr(kept), n_out))
+        return out, kept.astype(bool)
+
     def correlate(self, side, Y, N):
         """r (N x m) = Pearson correlation of the real part of every column of the resident field `side` with the columns
         of Y (T x m).  tools/array.py:76-88 without the (N + m)^2 corrcoef matrix."""
@@ -383,6 +398,16 @@ class Handle:
 
     def reset_timings(self):
         self._check(self._lib.xmca_reset_timings(self._h))
+
+    def pool_bytes(self):
+        """device memory the handle keeps for re-use (solver temporaries; include/xmca_hip.h xmca_pool_bytes)"""
+        n = ctypes.c_int64(0)
+        self._check(self._lib.xmca_pool_bytes(self._h, ctypes.byref(n)))
+        return int(n.value)
+
+    def trim_pool(self):
+        """give the kept device memory back to the driver"""
+        self._check(self._lib.xmca_trim_pool(self._h))
 
     # ---- kernel-level entry points --------------------------------------------------------------
     def gemm(self, A, B, a_kfast=True, b_nfast=True, alpha=1.0, upper_only=False, mirror=0, splits=0):

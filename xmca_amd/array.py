@@ -956,21 +956,23 @@ class MCA:
                 n_blocks = n_obs // block_size
                 rank = min([n_obs] + [X_surr[k].shape[1] for k in self._keys])
                 n_out = n_rot if is_rotated else rank
+                # the reference resamples cumulatively (X_surr is overwritten, array.py:1935-1943): replicate r sees the rows
+                # c_r = c_{r-1}[idx_r] of the original field.  The draws are made here in the reference's order, composed, and
+                # the device runs all replicates in one call, several at a time.
+                cum = np.arange(n_obs)
+                composed = np.empty((n_runs, n_obs), dtype=np.int64)
                 for run in range(n_runs):
-                    idx = {'left': None, 'right': None}
                     if on_left or on_right:
                         # one draw per replicate, like tools/array.py:136 (both sides share it when both are resampled)
                         pick = np.random.choice(n_blocks, size=n_blocks, replace=replace)
                         rows = (pick[:, None] * block_size + np.arange(block_size)[None, :]).reshape(-1)
-                        if on_left:
-                            idx['left'] = rows
-                        if on_right:
-                            idx['right'] = rows
-                    spec, kept = dev.bootstrap_run(n_obs, complexify, idx['left'], idx['right'], is_rotated, n_rot, max(power, 1),
-                                                   1e-8, n_out)
-                    if not kept:
-                        continue
-                    var_surr[mode:, run] = spec[:n_modes_max - mode]
+                        cum = cum[rows]
+                    composed[run] = cum
+                spec, kept = dev.bootstrap_runs(n_obs, complexify, composed if on_left else None, composed if on_right else None,
+                                                n_runs, is_rotated, n_rot, max(power, 1), 1e-8, n_out)
+                for run in range(n_runs):
+                    if kept[run]:
+                        var_surr[mode:, run] = spec[run, :n_modes_max - mode]
                 if strategy == 'standard':
                     break
                 continue

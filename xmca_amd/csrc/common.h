@@ -43,12 +43,17 @@ struct Error : std::runtime_error {
 // Re-use is safe without events because a pool serves exactly one stream: whatever still reads a returned block was
 // enqueued on that stream before whatever writes it next.  The calling thread names its pool with a PoolScope (API entry
 // points, lane threads); a DevBuf remembers the pool it came from and returns there from any thread.
-// Blocks above `keep_limit` in total are freed straight away; XMCA_POOL=0 switches pooling off.
+// Blocks above `keep_limit` in total (XMCA_POOL_LIMIT_GB, default 32) are freed straight away; XMCA_POOL=0 switches
+// pooling off; xmca_trim_pool returns what is held.
 struct DevPool {
   std::mutex mu;
   std::multimap<size_t, void*> blocks;     // capacity in bytes -> free block
   size_t held = 0;
-  size_t keep_limit = (size_t)96 << 30;
+  size_t keep_limit = [] {
+    const char* e = std::getenv("XMCA_POOL_LIMIT_GB");
+    const double gb = e ? std::atof(e) : 32.0;
+    return (size_t)((gb > 0.0 ? gb : 0.0) * (double)((size_t)1 << 30));
+  }();
   static bool enabled() {
     static const bool on = [] { const char* e = std::getenv("XMCA_POOL"); return !(e && e[0] == '0'); }();
     return on;

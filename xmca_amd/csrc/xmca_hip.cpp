@@ -512,23 +512,22 @@ void rule_n_lane(xmca_handle* h, int64_t T, int64_t Nx, int64_t Ny, int n_fields
   XMCA_HIP(hipStreamSynchronize(h->st));
 }
 
-template <typename TI>
-void rule_n_impl(xmca_handle* h, int64_t T, int64_t Nx, int64_t Ny, int n_fields, const double* ht_host, int rotated, int p,
-                 int power, double tol, int64_t run_begin, int64_t run_end, uint64_t seed, double* spectra, int* kept,
-                 int64_t n_out) {
+// number of replicates kept in flight (XMCA_RULE_N_LANES; measured in rule_n_impl's note above)
+static int lanes_for(int64_t eig_n, int64_t n_runs) {
   // measured on MI355X (scripts/rule_n_bench.py, surrogates/s with 1 / 2 / 3 / 4 lanes): C4 8.0 / 10.6 / 10.4 / 10.4,
   // C2-shaped EOF 25.8 / 32.9 / 33.1 / 32.3, C1-shaped (eigenproblems of 675) 109 / 191 / 265 / 337
   static const int lanes_env = [] { const char* e = std::getenv("XMCA_RULE_N_LANES"); return e ? std::max(1, std::min(8, std::atoi(e))) : 0; }();
-  const int64_t eig_n = std::min(T, n_fields == 2 ? std::min(Nx, Ny) : Nx);
   const int lanes_wanted = lanes_env ? lanes_env : (eig_n >= 2000 ? 2 : 4);
-  const int lanes = (int)std::min<int64_t>(lanes_wanted, std::max<int64_t>(run_end - run_begin, 1));
-  if (lanes <= 1) {
-    rule_n_lane<TI>(h, T, Nx, Ny, n_fields, ht_host, rotated, p, power, tol, run_begin, run_end, 0, 1, seed, spectra, kept, n_out);
-    return;
-  }
+  return (int)std::min<int64_t>(lanes_wanted, std::max<int64_t>(n_runs, 1));
+}
+
+// body(lane handle, j) on `lanes` host threads (lane 0 = the caller's handle on the calling thread); the first error is
+// rethrown after every lane has been joined; stage times and round counters of the lanes are added to the caller's.
+template <typename F>
+void run_lanes(xmca_handle* h, int lanes, F&& lane_body) {
   while ((int)h->lanes.size() < lanes - 1) {
     xmca_handle* lane = nullptr;
-    XMCA_CHECK(xmca_create(h->device, &lane) == XMCA_OK, XMCA_ERR_HIP, "rule_n: cannot create a lane (stream)");
+    XMCA_CHECK(xmca_create(h->device, &lane) == XMCA_OK, XMCA_ERR_HIP, "cannot create a lane (stream)");
     h->lanes.push_back(lane);
   }
   std::vector<std::exception_ptr> errs((size_t)lanes);
@@ -539,7 +538,8 @@ void rule_n_impl(xmca_handle* h, int64_t T, int64_t Nx, int64_t Ny, int n_fields
       ::xmca::PoolScope scope(&lh->pool);
       XMCA_HIP(hipSetDevice(h->device));
       lh->tm.enabled = h->tm.enabled;
-      rule_n_lane<TI>(lh, T, Nx, Ny, n_fields, ht_host, rotated, p, power, tol, run_begin, run_end, j, lanes, seed, spectra, kept, n_out);
+      lane_body(lh, j);
+      XMCA_HIP(hipStreamSynchronize(lh->st));
     } catch (...) {
       errs[(size_t)j] = std::current_exception();
       (void)hipStreamSynchronize(lh->st);
@@ -548,7 +548,6 @@ void rule_n_impl(xmca_handle* h, int64_t T, int64_t Nx, int64_t Ny, int n_fields
   for (int j = 1; j < lanes; ++j) threads.emplace_back(body, j);
   body(0);
   for (auto& t : threads) t.join();
-  // stage times and eigensolver round counters of the lanes are added to the caller's (they overlap in wall-clock time)
   for (xmca_handle* lane : h->lanes) {
     lane->tm.collect();
     for (const auto& name : lane->tm.order) {
@@ -564,6 +563,21 @@ void rule_n_impl(xmca_handle* h, int64_t T, int64_t Nx, int64_t Ny, int n_fields
   }
   for (auto& e : errs)
     if (e) std::rethrow_exception(e);
+}
+
+template <typename TI>
+void rule_n_impl(xmca_handle* h, int64_t T, int64_t Nx, int64_t Ny, int n_fields, const double* ht_host, int rotated, int p,
+                 int power, double tol, int64_t run_begin, int64_t run_end, uint64_t seed, double* spectra, int* kept,
+                 int64_t n_out) {
+  const int64_t eig_n = std::min(T, n_fields == 2 ? std::min(Nx, Ny) : Nx);
+  const int lanes = lanes_for(eig_n, run_end - run_begin);
+  if (lanes <= 1) {
+    rule_n_lane<TI>(h, T, Nx, Ny, n_fields, ht_host, rotated, p, power, tol, run_begin, run_end, 0, 1, seed, spectra, kept, n_out);
+    return;
+  }
+  run_lanes(h, lanes, [&](xmca_handle* lh, int j) {
+    rule_n_lane<TI>(lh, T, Nx, Ny, n_fields, ht_host, rotated, p, power, tol, run_begin, run_end, j, lanes, seed, spectra, kept, n_out);
+  });
 }
 
 // ---- bootstrapping: working copies on the device -----------------------------------------------------------------
@@ -624,6 +638,63 @@ void bootstrap_run_impl(xmca_handle* h, const double* ht_host, const int64_t* id
   ReplicateRunner<TI> runner(h, T, h->boot_N[0], n_fields == 2 ? h->boot_N[1] : 0, n_fields, ht_host, rotated, p, power, tol);
   XMCA_CHECK(n_out == (rotated ? (int64_t)p : runner.rank()), XMCA_ERR_INVALID, "bootstrap: n_out must be rank (unrotated) or p (rotated)");
   *kept = runner.run(f, spectrum, n_out);
+}
+
+// Replicates r = first, first + stride, ... of a bootstrap: rows of the ORIGINAL working copies (xmca_bootstrap_begin) are
+// gathered through the composed index of replicate r - the reference's cumulative resampling X <- X[idx_r] unrolled on
+// the host, c_r = c_{r-1}[idx_r] - so the replicates do not depend on each other on the device and can run in lanes.
+template <typename TI>
+void bootstrap_lane(xmca_handle* h, xmca_handle* src, const double* ht_host, const int64_t* idx_left, const int64_t* idx_right,
+                    int64_t n_runs, int64_t first, int64_t stride, int rotated, int p, int power, double tol, double* spectra,
+                    int* kept, int64_t n_out) {
+  const int n_fields = src->boot_fields;
+  const int64_t T = src->boot_T;
+  const int64_t* idx_host[2] = {idx_left, idx_right};
+  FieldData<TI> f[2];
+  DevBuf<int64_t> idx_dev[2];
+  ReplicateRunner<TI> runner(h, T, src->boot_N[0], n_fields == 2 ? src->boot_N[1] : 0, n_fields, ht_host, rotated, p, power, tol);
+  XMCA_CHECK(n_out == (rotated ? (int64_t)p : runner.rank()), XMCA_ERR_INVALID, "bootstrap: n_out must be rank (unrotated) or p (rotated)");
+  for (int64_t run = first; run < n_runs; run += stride) {
+    h->tm.begin("resample");
+    for (int s = 0; s < n_fields; ++s) {
+      const int64_t N = src->boot_N[s];
+      const size_t n = (size_t)T * N;
+      const DevBuf<TI>& W = boot_w<TI>(src)[s];
+      f[s].T = T; f[s].N = N; f[s].has_im = false; f[s].ext_re = nullptr;
+      if (idx_host[s]) {
+        XMCA_HIP(hipMemcpyAsync(idx_dev[s].ensure((size_t)T), idx_host[s] + run * T, sizeof(int64_t) * T, hipMemcpyHostToDevice, h->st));
+        hipLaunchKernelGGL((gather_rows_kernel<TI>), ew_grid((int64_t)n, 4), dim3(EW_BLOCK), 0, h->st, W.get(), f[s].re.ensure(n),
+                           idx_dev[s].get(), (int)T, N);
+      } else {
+        XMCA_HIP(hipMemcpyAsync(f[s].re.ensure(n), W.get(), sizeof(TI) * n, hipMemcpyDeviceToDevice, h->st));
+      }
+      center_columns<TI>(h, f[s].re.get(), T, N);   // MCA(...) ctor, array.py:117
+      XMCA_HIP(hipGetLastError());
+    }
+    h->tm.end();
+    kept[run] = runner.run(f, spectra + run * n_out, n_out);
+    XMCA_HIP(hipStreamSynchronize(h->st));          // the index buffers are overwritten by the next replicate's upload
+  }
+}
+
+template <typename TI>
+void bootstrap_runs_impl(xmca_handle* h, const double* ht_host, const int64_t* idx_left, const int64_t* idx_right, int64_t n_runs,
+                         int rotated, int p, int power, double tol, double* spectra, int* kept, int64_t n_out) {
+  const int n_fields = h->boot_fields;
+  const int64_t T = h->boot_T;
+  XMCA_CHECK(n_fields >= 1 && T > 0, XMCA_ERR_STATE, "bootstrap: call xmca_bootstrap_begin first");
+  for (const int64_t* idx : {idx_left, idx_right})
+    if (idx)
+      for (int64_t i = 0; i < n_runs * T; ++i) XMCA_CHECK(idx[i] >= 0 && idx[i] < T, XMCA_ERR_INVALID, "bootstrap: row index out of range");
+  const int64_t eig_n = std::min(T, n_fields == 2 ? std::min(h->boot_N[0], h->boot_N[1]) : h->boot_N[0]);
+  const int lanes = lanes_for(eig_n, n_runs);
+  if (lanes <= 1) {
+    bootstrap_lane<TI>(h, h, ht_host, idx_left, idx_right, n_runs, 0, 1, rotated, p, power, tol, spectra, kept, n_out);
+    return;
+  }
+  run_lanes(h, lanes, [&](xmca_handle* lh, int j) {
+    bootstrap_lane<TI>(lh, h, ht_host, idx_left, idx_right, n_runs, j, lanes, rotated, p, power, tol, spectra, kept, n_out);
+  });
 }
 
 }  // namespace
@@ -818,6 +889,19 @@ int xmca_bootstrap_run(xmca_handle* h, const double* hilbert_col, const int64_t*
   API_END(h)
 }
 
+int xmca_bootstrap_runs(xmca_handle* h, const double* hilbert_col, const int64_t* idx_left, const int64_t* idx_right, int64_t n_runs,
+                        int rotated, int p, int power, double tol, double* spectra_out, int* kept_out, int64_t n_out) {
+  API_BEGIN(h)
+  XMCA_CHECK(spectra_out && kept_out && n_out >= 1 && n_runs >= 0, XMCA_ERR_INVALID, "bootstrap: output buffers missing");
+  XMCA_CHECK(!rotated || (p >= 2 && power >= 1), XMCA_ERR_INVALID, "bootstrap: rotation needs n_rot >= 2 and power >= 1");
+  if (h->dtype == XMCA_F32)
+    bootstrap_runs_impl<float>(h, hilbert_col, idx_left, idx_right, n_runs, rotated, p, power, tol, spectra_out, kept_out, n_out);
+  else
+    bootstrap_runs_impl<double>(h, hilbert_col, idx_left, idx_right, n_runs, rotated, p, power, tol, spectra_out, kept_out, n_out);
+  h->tm.collect();
+  API_END(h)
+}
+
 int xmca_correlate(xmca_handle* h, int side, const double* Y, int64_t T, int64_t m, double* r_out) {
   API_BEGIN(h)
   XMCA_CHECK(side == 0 || side == 1, XMCA_ERR_INVALID, "correlate: side must be 0 or 1");
@@ -929,6 +1013,26 @@ int xmca_reset_timings(xmca_handle* h) {
   h->ews.w64.round_ms = h->ews.w32.round_ms = 0.0;
   h->ews.w64.round_launches = h->ews.w32.round_launches = 0;
   return XMCA_OK;
+}
+
+int xmca_pool_bytes(xmca_handle* h, int64_t* held_bytes) {
+  if (!h || !held_bytes) return XMCA_ERR_INVALID;
+  size_t total = 0;
+  { std::lock_guard<std::mutex> g(h->pool.mu); total += h->pool.held; }
+  for (xmca_handle* lane : h->lanes) { std::lock_guard<std::mutex> g(lane->pool.mu); total += lane->pool.held; }
+  *held_bytes = (int64_t)total;
+  return XMCA_OK;
+}
+
+int xmca_trim_pool(xmca_handle* h) {
+  API_BEGIN(h)
+  XMCA_HIP(hipStreamSynchronize(h->st));
+  h->pool.trim();
+  for (xmca_handle* lane : h->lanes) {
+    XMCA_HIP(hipStreamSynchronize(lane->st));
+    lane->pool.trim();
+  }
+  API_END(h)
 }
 
 int xmca_gemm(xmca_handle* h, const void* A, int64_t lda, int a_kfast, const void* B, int64_t ldb, int b_nfast, double* C, int M,
