@@ -47,7 +47,16 @@ def test_c3_at_full_size_matches_reference():
     every 5th time step): all 5000 singular values, the 20 leading loadings of both fields, R, Phi, norms, variance, PCs
     and the Varimax iteration count."""
     gold = np.load(os.path.join(GOLDEN_DIR, "config_c3_full.npz"))
-    _check_config(gold, "c3_full", True, 20, 4, "device")
+    m = _check_config(gold, "c3_full", True, 20, 4, "device")
+    # every non-null vector against the 20 leading ones and against a sample of the noise floor (2300 modes at 3e-5..1e-4
+    # sigma_1): weak rows are formed by cancelling products and had |u_18^H u_2499| = 7e-4 before Solver::project_out_rows
+    sel = np.r_[0:20, 20:2500:31, 2490:2500]
+    for key in m._keys:
+        V = np.asarray(m._V[key][:, :2500])
+        G = V[:, sel].conj().T @ V
+        assert np.max(np.abs(G - np.eye(2500)[sel])) < 1e-6, key
+    info = m._device().solve_info()
+    assert info[0]["sweeps"] == 0 and info[2]["sweeps"] > 0          # no eigen-decomposition of the first field (Cholesky factor)
 
 
 def _check_config(gold, name, cplx, n_rot, power, preprocess):
@@ -102,6 +111,7 @@ def _check_config(gold, name, cplx, n_rot, power, preprocess):
     # (two fields: sigma^2 = lambda(K K^H) - orthogonality of weak modes degrades like 5e-14 (sigma_1 / sigma_m)^2)
     V = m._V.head("left", n_rot)
     assert np.max(np.abs(V.conj().T @ V - np.eye(n_rot))) < (1e-4 if f32 else 1e-6 if len(fields) == 2 else 1e-9)
+    return m
 
 
 @pytest.mark.parametrize("n,cplx", [(2920, False), (2501, True)])

@@ -212,6 +212,21 @@ __global__ void chol_max_diag_kernel(const double* __restrict__ Gr, int64_t ld, 
   if ((threadIdx.x & 63) == 0 && mx > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(mx));
 }
 
+// smallest and largest diagonal entry of a matrix with a positive diagonal (bit patterns order like the values)
+__global__ void chol_minmax_diag_kernel(const double* __restrict__ Gr, int64_t ld, int n, unsigned long long* __restrict__ out) {
+  double mx = 0.0, mn = HUGE_VAL;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const double v = Gr[(int64_t)i * ld + i];
+    mx = fmax(mx, v);
+    mn = fmin(mn, v);
+  }
+  for (int o = 32; o > 0; o >>= 1) { mx = fmax(mx, __shfl_xor(mx, o)); mn = fmin(mn, __shfl_xor(mn, o)); }
+  if ((threadIdx.x & 63) == 0) {
+    if (mx > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(mx));
+    if (mn >= 0.0) atomicMin(out + 1, (unsigned long long)__double_as_longlong(mn));
+  }
+}
+
 // C = alpha * rs * cs * opA(A) * opB(B) on complex planes through 1-4 real MFMA GEMMs.
 //   conj flags negate the imaginary plane of the operand; `herm` computes only the upper block triangle and
 //   mirrors (C must then be Hermitian by construction).

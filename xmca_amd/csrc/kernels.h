@@ -87,6 +87,50 @@ __global__ void add_diag_kernel(double* __restrict__ G, int64_t ld, int n, doubl
   if (i < n) G[(int64_t)i * ld + i] += v;
 }
 
+// largest |C_ij| / sqrt(C_ii C_jj), i != j, of an n x n Hermitian Gram matrix with a positive diagonal (rows with a zero
+// diagonal - null modes - are skipped): how far a set of vectors is from orthogonal.  One row per workgroup (grid-stride).
+__global__ void coherence_kernel(const double* __restrict__ Cr, const double* __restrict__ Ci, int n, int n_check,
+                                 unsigned long long* __restrict__ out) {
+  double worst = 0.0;
+  for (int i = blockIdx.x; i < n_check; i += gridDim.x) {      // the leading n_check rows / columns of the n x n matrix
+    const double dii = Cr[(int64_t)i * n + i];
+    if (!(dii > 0.0)) continue;
+    for (int j = threadIdx.x; j < n_check; j += blockDim.x) {
+      const double djj = Cr[(int64_t)j * n + j];
+      if (j == i || !(djj > 0.0)) continue;
+      const double re = Cr[(int64_t)i * n + j], im = Ci ? Ci[(int64_t)i * n + j] : 0.0;
+      const double c = sqrt((re * re + im * im) / (dii * djj));
+      worst = c > worst || !(c == c) ? (c == c ? c : HUGE_VAL) : worst;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) worst = fmax(worst, __shfl_xor(worst, o));
+  if ((threadIdx.x & 63) == 0 && worst > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(worst));
+}
+
+// dinv[r] = 1 / Re sum_k A[r][k] conj(B[r][k])   (rows of two r x n plane pairs; 0 when the sum is not positive)
+__global__ void row_dot_inverse_kernel(const double* __restrict__ Ar, const double* __restrict__ Ai, const double* __restrict__ Br,
+                                       const double* __restrict__ Bi, int n, double* __restrict__ dinv) {
+  __shared__ double red[4];
+  const int64_t row = (int64_t)blockIdx.x * n;
+  double acc = 0.0;
+  for (int k = threadIdx.x; k < n; k += blockDim.x) {
+    acc += Ar[row + k] * Br[row + k];
+    if (Ai) acc += Ai[row + k] * Bi[row + k];
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double d = (red[0] + red[1]) + (red[2] + red[3]);
+    dinv[blockIdx.x] = d > 0.0 ? 1.0 / d : 0.0;
+  }
+}
+
+// x[i] += v
+__global__ void add_const_kernel(double* __restrict__ x, int64_t n, double v) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] += v;
+}
+
 // Ht[t][s] = col[(t - s) mod T]  (circulant operator from its first column)
 template <typename TO>
 __global__ void circulant_kernel(const double* __restrict__ col, int T, TO* __restrict__ out) {

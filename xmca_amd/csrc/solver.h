@@ -595,9 +595,12 @@ class Solver {
   }
 
   void reduce_analytic(const FieldData<TI>& f, const Analytic& an, AReduced& R, EvdInfo* info, bool want_vectors) {
-    const int m = an.m;
     CPlanes Gy;
     analytic_gram(f, an, Gy);
+    reduce_analytic_gram(Gy, an, R, info, want_vectors);
+  }
+  void reduce_analytic_gram(const CPlanes& Gy, const Analytic& an, AReduced& R, EvdInfo* info, bool want_vectors) {
+    const int m = an.m;
     tm.begin("eigh");
     if (want_vectors) R.Wh.ensure((size_t)m * m, true);
     R.s.ensure((size_t)m);
@@ -648,7 +651,40 @@ class Solver {
   //     H_w[i][j] = p_i^H H p_j = El_i Er_j^H / dof^2        (norm sigma_{ns+1}^2, error eps sigma_1 sigma_w)
   // and its eigen-decomposition H_w = Z^H L Z - a nearly diagonal matrix, two or three Jacobi sweeps - replaces sigma and
   // rotates the weak rows: Er_w <- Z Er_w, El_w <- Z El_w.  Up to three levels, as in refine_by_deflation; same switch.
-  void refine_weak_block(CPlanes& Er, CPlanes& El, int nv, int m, double dof, SolveResult& out, bool cplx = true) {
+  // Rows W = E[ns..nv) made orthogonal to the rows S = E[s0..ns) under the metric G (m x m Hermitian):
+  //   W_w -= sum_s  (S_s G W_w^H)^* / (S_s G S_s^H)  S_s.
+  // E_l rows are the left singular vectors' coefficients (u_i ~ X~a^H E_l,i^H, metric Gy_a), E_r rows the right ones' (metric
+  // Gy_b).  A weak row is formed by products that cancel from lambda_1 down to its own size, which leaves it a component
+  // along the strong rows of ~eps lambda_1 / lambda_w - times s_a1 / s_a,w once it is back in grid space: measured at
+  // full-size C3 |u_18^H u_2499| = 7e-4 (right side 4e-6) with every weak-weak product below 8e-8.  The exact vectors are
+  // orthogonal, so the component is error and is projected out (the strong rows are mutually orthogonal to 1e-11).
+  void project_out_rows(CPlanes& E, const CPlanes& G, int s0, int ns, int nv, int m, bool cplx) {
+    const int k = ns - s0, nw = nv - ns;
+    if (k <= 0 || nw <= 0) return;
+    CPlanes T1, C;
+    DevBuf<double> dinv;
+    T1.ensure((size_t)k * m, cplx);
+    C.ensure((size_t)k * nw, cplx);
+    dinv.ensure((size_t)k);
+    double* sr = E.r() + (int64_t)s0 * m;
+    double* si = cplx ? E.im.get() + (int64_t)s0 * m : nullptr;
+    double* wr = E.r() + (int64_t)ns * m;
+    double* wi = cplx ? E.im.get() + (int64_t)ns * m : nullptr;
+    cgemm<double>(st, gws, sr, si, m, true, false, G.r(), G.i(cplx), m, true, false, T1.r(), T1.i(cplx), m, k, m, m, 1.0, nullptr, nullptr,
+                  false);
+    hipLaunchKernelGGL(row_dot_inverse_kernel, dim3(k), dim3(256), 0, st, T1.r(), T1.i(cplx), sr, si, m, dinv.get());
+    // C[s][w] = (S_s G W_w^H) / d_s ;  W -= C^H S
+    cgemm<double>(st, gws, T1.r(), T1.i(cplx), m, true, false, wr, wi, m, false, true, C.r(), C.i(cplx), nw, k, nw, m, 1.0, dinv.get(),
+                  nullptr, false);
+    cgemm<double>(st, gws, C.r(), C.i(cplx), nw, false, true, sr, si, m, true, false, wr, wi, m, nw, m, k, -1.0, nullptr, nullptr, false,
+                  1.0);
+    XMCA_HIP(hipGetLastError());
+    XMCA_HIP(hipStreamSynchronize(st));       // temporaries
+  }
+
+  // Ga / Gb: metrics of the left / right coefficient rows (Gy_a, Gy_b) for the projection above, or null
+  void refine_weak_block(CPlanes& Er, CPlanes& El, int nv, int m, double dof, SolveResult& out, bool cplx = true,
+                         const CPlanes* Ga = nullptr, const CPlanes* Gb = nullptr) {
     if constexpr (std::is_same<TI, float>::value) return;        // float32 fields: sigma is resolved to 6e-8 sigma_1 at best
     static const double thr = [] { const char* e = std::getenv("XMCA_DEFLATE_BELOW"); return e ? std::atof(e) : 1e-3; }();   // 0: off
     if (thr <= 0.0 || nv <= 1 || !(out.sigma[0] > 0.0)) return;
@@ -682,6 +718,10 @@ class Solver {
         if (cplx) XMCA_HIP(hipMemcpyAsync(im, Tmp.im.get(), sizeof(double) * (size_t)nw * m, hipMemcpyDeviceToDevice, st));
       }
       XMCA_HIP(hipStreamSynchronize(st));
+      if (Ga && Gb) {
+        project_out_rows(Er, *Gb, done, ns, nv, m, cplx);
+        project_out_rows(El, *Ga, done, ns, nv, m, cplx);
+      }
       tm.end();
       for (int j = 0; j < nw; ++j) out.sigma[ns + j] = std::sqrt(std::max(lam[j], 0.0));
       done = ns;
@@ -693,6 +733,70 @@ class Solver {
     for (int k = 0; k < n_fields; ++k)
       if (fields[k].N <= fields[k].T || fields[k].has_im) return false;
     return true;
+  }
+
+  // M with M^H M = G (n x n Hermitian, positive semi-definite) as the UNSHIFTED Cholesky factor - the cheap replacement of
+  // the eigen-factor S W^H of the field that the one-sided routes decompose.  Any factor serves them: with H = M G_b M^H / dof^2
+  // = P L P^H, q = M^H p solves G_a G_b q = sigma^2 dof^2 q, and the singular vectors are X~b^H q and X~a^H G_b q, whatever M is.
+  // Both factors are exact for a matrix eps |G| away from G; what the eigen-factor has on top is the eigensolver's handling
+  // of graded spectra (LR step), so a factor whose pivots span more than `1e8` (variances) is refused and the caller
+  // decomposes the field as before.  No shift (a ridge delta moves sigma_i^2 by delta / lambda_a,i, relative): the one null
+  // direction that is always there is handled exactly instead -
+  //   analytic subspace: the zero-frequency row/column of a centered field (G_00 ~ 0): factor the block behind it;
+  //   time space (null_is_mean): the constant vector of a centered field: G + mean(diag) 1 1^T / n has the same eigenpairs
+  //   except for that one, and G_b 1 = 0 keeps it out of H.
+  bool factor_by_cholesky(const CPlanes& G, int n, bool cplx, bool null_is_mean, CPlanes& M) {
+    static const bool on = [] { const char* e = std::getenv("XMCA_CHOLESKY_FACTOR"); return !(e && e[0] == '0'); }();
+    if (!on || !cholesky_enabled() || n < 2) return false;
+    tm.begin("cholesky");
+    const size_t nn = (size_t)n * n;
+    M.ensure(nn, cplx);
+    XMCA_HIP(hipMemcpyAsync(M.r(), G.r(), sizeof(double) * nn, hipMemcpyDeviceToDevice, st));
+    if (cplx) XMCA_HIP(hipMemcpyAsync(M.im.get(), G.im.get(), sizeof(double) * nn, hipMemcpyDeviceToDevice, st));
+    DevBuf<unsigned long long> mm;
+    unsigned long long init[2] = {0ull, 0x7ff0000000000000ull};
+    double g00 = 0.0;
+    XMCA_HIP(hipMemcpyAsync(mm.ensure(2), init, sizeof(init), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(chol_minmax_diag_kernel, dim3(std::min(ceil_div(n, 256), 64)), dim3(256), 0, st, M.r(), (int64_t)n, n, mm.get());
+    unsigned long long bits[2];
+    XMCA_HIP(hipMemcpyAsync(bits, mm.get(), sizeof(bits), hipMemcpyDeviceToHost, st));
+    XMCA_HIP(hipMemcpyAsync(&g00, M.r(), sizeof(double), hipMemcpyDeviceToHost, st));
+    XMCA_HIP(hipStreamSynchronize(st));
+    double maxdiag = 0.0;
+    std::memcpy(&maxdiag, &bits[0], sizeof(double));
+    bool ok = maxdiag > 0.0 && std::isfinite(maxdiag);
+    int k0 = 0;
+    if (ok) {
+      if (null_is_mean) {
+        hipLaunchKernelGGL(add_const_kernel, ew_grid((int64_t)nn), dim3(EW_BLOCK), 0, st, M.r(), (int64_t)nn, maxdiag / (double)n);
+      } else if (std::fabs(g00) < 1e-12 * maxdiag) {
+        k0 = 1;
+      }
+      const int64_t off = (int64_t)k0 * (n + 1);
+      ok = cholesky_upper(st, gws, M.r() + off, cplx ? M.im.get() + off : nullptr, n - k0, n, 0.0);
+    }
+    if (ok) {
+      if (k0) {   // row 0 and column 0 of the factor are zero: the null mode stays a null mode
+        XMCA_HIP(hipMemsetAsync(M.r(), 0, sizeof(double) * n, st));
+        XMCA_HIP(hipMemset2DAsync(M.r(), sizeof(double) * n, 0, sizeof(double), (size_t)n, st));
+        if (cplx) {
+          XMCA_HIP(hipMemsetAsync(M.im.get(), 0, sizeof(double) * n, st));
+          XMCA_HIP(hipMemset2DAsync(M.im.get(), sizeof(double) * n, 0, sizeof(double), (size_t)n, st));
+        }
+      }
+      XMCA_HIP(hipMemcpyAsync(mm.get(), init, sizeof(init), hipMemcpyHostToDevice, st));
+      const int64_t off = (int64_t)k0 * (n + 1);
+      hipLaunchKernelGGL(chol_minmax_diag_kernel, dim3(std::min(ceil_div(n - k0, 256), 64)), dim3(256), 0, st, M.r() + off, (int64_t)n, n - k0,
+                         mm.get());
+      XMCA_HIP(hipMemcpyAsync(bits, mm.get(), sizeof(bits), hipMemcpyDeviceToHost, st));
+      XMCA_HIP(hipStreamSynchronize(st));
+      double rmax = 0.0, rmin = 0.0;
+      std::memcpy(&rmax, &bits[0], sizeof(double));
+      std::memcpy(&rmin, &bits[1], sizeof(double));
+      ok = rmax > 0.0 && rmin > 1e-4 * rmax;          // pivots r_ii^2 within 1e8 of each other
+    }
+    tm.end();
+    return ok;
   }
 
   void solve_analytic(const FieldData<TI>* fields, int n_fields, int n_vec_req, SolveResult& out) {
@@ -720,7 +824,16 @@ class Solver {
         return;
       }
     }
-    reduce_analytic(A, an, Ra, &out.evd_info[0], n_fields == 2 || n_vec != 0);
+    static const bool one_sided_on = [] { const char* e = std::getenv("XMCA_ONE_SIDED"); return !(e && e[0] == '0'); }();
+    CPlanes Fm, Gya;                   // factor of Gy_a used by the one-sided route: Cholesky (Fm) or eigen (Ra.s, Ra.Wh)
+    bool by_chol = false;
+    if (n_fields == 2 && one_sided_on) {
+      analytic_gram(A, an, Gya);
+      by_chol = factor_by_cholesky(Gya, m, true, false, Fm);
+      if (!by_chol) reduce_analytic_gram(Gya, an, Ra, &out.evd_info[0], true);
+    } else {
+      reduce_analytic(A, an, Ra, &out.evd_info[0], n_fields == 2 || n_vec != 0);
+    }
     if (n_fields == 1) {
       for (int i = 0; i < m; ++i) out.sigma[i] = std::max(Ra.lam[i], 0.0) / dof;
       out.ldv[0] = A.N;
@@ -730,50 +843,86 @@ class Solver {
       return;
     }
     const FieldData<TI>& B = fields[1];
-    static const bool one_sided_on = [] { const char* e = std::getenv("XMCA_ONE_SIDED"); return !(e && e[0] == '0'); }();
     if (one_sided_on) {
-      // second field as an operator (see solve_one_sided): H = (S_a Wh_a) Gy_b (S_a Wh_a)^H / dof^2
-      CPlanes Gyb, M1, H, Ph;
+      // second field as an operator (see solve_one_sided): H = M Gy_b M^H / dof^2 with M^H M = Gy_a - the Cholesky factor
+      // (factor_by_cholesky: no eigen-decomposition of the first field at all) or the eigen-factor S_a Wh_a
+      CPlanes Gyb;
       analytic_gram(B, an, Gyb);
-      tm.begin("kernel");
-      M1.ensure((size_t)m * m, true);
-      H.ensure((size_t)m * m, true);
-      cgemm<double>(st, gws, Ra.Wh.r(), Ra.Wh.im.get(), m, true, false, Gyb.r(), Gyb.im.get(), m, true, false, M1.r(), M1.im.get(), m, m, m,
-                    m, 1.0, Ra.s.get(), nullptr, false);
-      cgemm<double>(st, gws, M1.r(), M1.im.get(), m, true, false, Ra.Wh.r(), Ra.Wh.im.get(), m, false, true, H.r(), H.im.get(), m, m, m, m,
-                    1.0 / (dof * dof), nullptr, Ra.s.get(), true);
-      tm.end();
-      std::vector<double> lam;
-      tm.begin("kernel_svd");
-      if (n_vec > 0) Ph.ensure((size_t)m * m, true);
-      hermitian_evd(st, ews, H.r(), H.im.get(), m, m, lam, nullptr, n_vec > 0 ? Ph.r() : nullptr, n_vec > 0 ? Ph.im.get() : nullptr, m,
-                    &out.evd_info[2]);
-      XMCA_HIP(hipStreamSynchronize(st));
-      tm.end();
-      for (int i = 0; i < m; ++i) out.sigma[i] = std::sqrt(std::max(lam[i], 0.0));
       out.ldv[0] = A.N;
       out.ldv[1] = B.N;
-      if (n_vec == 0) return;
-      tm.begin("backproject");
-      // E_right = (Ph diag(s_a)) Wh_a (rows = conj of the subspace coefficients of F_a p_m),  E_left = E_right Gy_b
-      CPlanes Ws, Er, El;
-      Ws.ensure((size_t)nv * m, true);
-      Er.ensure((size_t)nv * m, true);
-      El.ensure((size_t)nv * m, true);
-      XMCA_HIP(hipMemcpyAsync(Ws.r(), Ph.r(), sizeof(double) * (size_t)nv * m, hipMemcpyDeviceToDevice, st));
-      XMCA_HIP(hipMemcpyAsync(Ws.im.get(), Ph.im.get(), sizeof(double) * (size_t)nv * m, hipMemcpyDeviceToDevice, st));
-      hipLaunchKernelGGL(scale_kernel, ew_grid((int64_t)nv * m), dim3(EW_BLOCK), 0, st, Ws.r(), Ws.im.get(), (int64_t)m, nv, m, Ra.s.get(),
-                         0, 0);
-      cgemm<double>(st, gws, Ws.r(), Ws.im.get(), m, true, false, Ra.Wh.r(), Ra.Wh.im.get(), m, true, false, Er.r(), Er.im.get(), m, nv, m,
-                    m, 1.0, nullptr, nullptr, false);
-      cgemm<double>(st, gws, Er.r(), Er.im.get(), m, true, false, Gyb.r(), Gyb.im.get(), m, true, false, El.r(), El.im.get(), m, nv, m, m,
-                    1.0, nullptr, nullptr, false);
-      tm.end();
-      refine_weak_block(Er, El, nv, m, dof, out);
-      tm.begin("backproject");
-      analytic_project(B, an, Er.r(), Er.im.get(), nv, n_vec, out.Vt[1]);
-      analytic_project(A, an, El.r(), El.im.get(), nv, n_vec, out.Vt[0]);
-      tm.end();
+      // returns false when the Cholesky factor turned out not to be good enough (left vectors not orthogonal: see below)
+      auto with_factor = [&](const CPlanes& Mf, const double* ms, bool guard) -> bool {
+        CPlanes M1, H, Ph;
+        tm.begin("kernel");
+        M1.ensure((size_t)m * m, true);
+        H.ensure((size_t)m * m, true);
+        cgemm<double>(st, gws, Mf.r(), Mf.im.get(), m, true, false, Gyb.r(), Gyb.im.get(), m, true, false, M1.r(), M1.im.get(), m, m, m,
+                      m, 1.0, ms, nullptr, false);
+        cgemm<double>(st, gws, M1.r(), M1.im.get(), m, true, false, Mf.r(), Mf.im.get(), m, false, true, H.r(), H.im.get(), m, m, m, m,
+                      1.0 / (dof * dof), nullptr, ms, true);
+        tm.end();
+        std::vector<double> lam;
+        tm.begin("kernel_svd");
+        if (n_vec > 0) Ph.ensure((size_t)m * m, true);
+        hermitian_evd(st, ews, H.r(), H.im.get(), m, m, lam, nullptr, n_vec > 0 ? Ph.r() : nullptr, n_vec > 0 ? Ph.im.get() : nullptr, m,
+                      &out.evd_info[2]);
+        XMCA_HIP(hipStreamSynchronize(st));
+        tm.end();
+        for (int i = 0; i < m; ++i) out.sigma[i] = std::sqrt(std::max(lam[i], 0.0));
+        if (n_vec == 0) return true;
+        tm.begin("backproject");
+        // E_right = Ph M (rows = conj of the subspace coefficients of q_m = M^H p_m),  E_left = E_right Gy_b
+        CPlanes Ws, Er, El;
+        Ws.ensure((size_t)nv * m, true);
+        Er.ensure((size_t)nv * m, true);
+        El.ensure((size_t)nv * m, true);
+        XMCA_HIP(hipMemcpyAsync(Ws.r(), Ph.r(), sizeof(double) * (size_t)nv * m, hipMemcpyDeviceToDevice, st));
+        XMCA_HIP(hipMemcpyAsync(Ws.im.get(), Ph.im.get(), sizeof(double) * (size_t)nv * m, hipMemcpyDeviceToDevice, st));
+        if (ms)
+          hipLaunchKernelGGL(scale_kernel, ew_grid((int64_t)nv * m), dim3(EW_BLOCK), 0, st, Ws.r(), Ws.im.get(), (int64_t)m, nv, m, ms, 0, 0);
+        cgemm<double>(st, gws, Ws.r(), Ws.im.get(), m, true, false, Mf.r(), Mf.im.get(), m, true, false, Er.r(), Er.im.get(), m, nv, m,
+                      m, 1.0, nullptr, nullptr, false);
+        cgemm<double>(st, gws, Er.r(), Er.im.get(), m, true, false, Gyb.r(), Gyb.im.get(), m, true, false, El.r(), El.im.get(), m, nv, m, m,
+                      1.0, nullptr, nullptr, false);
+        tm.end();
+        refine_weak_block(Er, El, nv, m, dof, out, true, &Gya, &Gyb);
+        if (guard && nv > 1) {
+          // The left vectors are u_i ~ X~a^H g_i with g_i = E_left,i^H: their Gram matrix is E_l Gy_a E_l^H (nv x nv, two small
+          // products).  On spectra graded over many decades E_l = E_r Gy_b cancels down to the weak rows and the Cholesky
+          // factor - unlike the eigen-factor, whose weak rows are small numbers to begin with - leaves u_weak with a component
+          // along the strong modes that project_out_rows has to remove (2e-8 left on the 10-decade probe, 4e-8 at C3 - the leading
+          // modes among themselves, the same with either factor).  Above 1e-6 the factor is not trusted: decompose the field.
+          tm.begin("orthogonality_check");
+          CPlanes T1, C;
+          DevBuf<double> coh;
+          T1.ensure((size_t)nv * m, true);
+          C.ensure((size_t)nv * nv, true);
+          cgemm<double>(st, gws, El.r(), El.im.get(), m, true, false, Gya.r(), Gya.im.get(), m, true, false, T1.r(), T1.im.get(), m, nv, m, m,
+                        1.0, nullptr, nullptr, false);
+          cgemm<double>(st, gws, T1.r(), T1.im.get(), m, true, false, El.r(), El.im.get(), m, false, true, C.r(), C.im.get(), nv, nv, nv, m,
+                        1.0, nullptr, nullptr, false);
+          XMCA_HIP(hipMemsetAsync(coh.ensure(1), 0, sizeof(double), st));
+          int n_check = 0;                                     // null modes carry arbitrary vectors
+          while (n_check < nv && out.sigma[n_check] > 1e-9 * out.sigma[0]) ++n_check;
+          hipLaunchKernelGGL(coherence_kernel, dim3(std::min(nv, 1024)), dim3(256), 0, st, C.r(), C.im.get(), nv, n_check,
+                             reinterpret_cast<unsigned long long*>(coh.get()));
+          double worst = 0.0;
+          XMCA_HIP(hipMemcpyAsync(&worst, coh.get(), sizeof(double), hipMemcpyDeviceToHost, st));
+          XMCA_HIP(hipStreamSynchronize(st));
+          tm.end();
+          static const bool trace = std::getenv("XMCA_SOLVE_TRACE") != nullptr;
+          if (trace) std::fprintf(stderr, "[xmca solve] Cholesky factor: left-vector coherence %.3e over %d modes\n", worst, n_check);
+          if (!(worst < 1e-6)) return false;
+        }
+        tm.begin("backproject");
+        analytic_project(B, an, Er.r(), Er.im.get(), nv, n_vec, out.Vt[1]);
+        analytic_project(A, an, El.r(), El.im.get(), nv, n_vec, out.Vt[0]);
+        tm.end();
+        return true;
+      };
+      if (by_chol && with_factor(Fm, nullptr, true)) return;
+      if (by_chol) reduce_analytic_gram(Gya, an, Ra, &out.evd_info[0], true);
+      with_factor(Ra.Wh, Ra.s.get(), false);
       return;
     }
     reduce_analytic(B, an, Rb, &out.evd_info[1], true);
