@@ -126,6 +126,18 @@ __global__ void row_dot_inverse_kernel(const double* __restrict__ Ar, const doub
   }
 }
 
+// out[r] = sum_k A[r][k]   (n x n plane, one row per workgroup)
+__global__ void row_sum_kernel(const double* __restrict__ A, int n, double* __restrict__ out) {
+  __shared__ double red[4];
+  const int64_t row = (int64_t)blockIdx.x * n;
+  double acc = 0.0;
+  for (int k = threadIdx.x; k < n; k += blockDim.x) acc += A[row + k];
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // x[i] += v
 __global__ void add_const_kernel(double* __restrict__ x, int64_t n, double v) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] += v;

@@ -151,6 +151,13 @@ class Solver {
     R.r = (int)std::min(f.T, f.N);
     if (!R.reduced) return;
     gram(f, cplx, G);
+    reduce_field_gram(f, cplx, R, G, info, want_vectors);
+  }
+  // ... from the Gram matrix G of f (T x T)
+  void reduce_field_gram(const FieldData<TI>& f, bool cplx, Reduced& R, const CPlanes& G, EvdInfo* info, bool want_vectors = true) {
+    const int T = (int)f.T;
+    R.reduced = true;
+    R.r = T;
     tm.begin("eigh");
     if (want_vectors) R.Z.ensure((size_t)T * T, cplx);
     R.s.ensure((size_t)T);
@@ -180,8 +187,9 @@ class Solver {
   // n_vec < 0: all modes
   void solve(const FieldData<TI>* fields, int n_fields, bool cplx, int n_vec_req, SolveResult& out) {
     out.weak_refined = false;            // (the caller may hand in the result object of an earlier solve)
+    for (EvdInfo& e : out.evd_info) e = EvdInfo();
     solve_core(fields, n_fields, cplx, n_vec_req, out);
-    if (n_fields == 2 && !out.weak_refined) refine_by_deflation(fields, cplx, out);
+    if (n_fields == 2) refine_by_deflation(fields, cplx, out);
   }
 
   // -------------------------------------------------------------------------------------------------------------
@@ -219,12 +227,14 @@ class Solver {
     if constexpr (!std::is_same<TI, double>::value) {
       return;
     } else {
-      static const double thr = [] { const char* e = std::getenv("XMCA_DEFLATE_BELOW"); return e ? std::atof(e) : 1e-3; }();   // 0: off
+      static const double thr_plain = [] { const char* e = std::getenv("XMCA_DEFLATE_BELOW"); return e ? std::atof(e) : 1e-3; }();   // 0: off
       const int n_vec = out.n_vec;
-      if (thr <= 0.0 || n_vec <= 1 || out.sigma.empty() || !(out.sigma[0] > 0.0)) return;
+      if (thr_plain <= 0.0 || n_vec <= 1 || out.sigma.empty() || !(out.sigma[0] > 0.0)) return;
       const int T = (int)fields[0].T;
       int done = 0;
-      for (int level = 0; level < 3; ++level) {
+      bool tail_refined = out.weak_refined;      // the solve that produced the current tail refined its weak block itself:
+      for (int level = 0; level < 3; ++level) {  // its modes are good down to 1e-5 of its top instead of 1e-3
+        const double thr = tail_refined ? std::min(thr_plain, 1e-5) : thr_plain;
         const double top = out.sigma[done];
         if (!(top > 0.0)) break;
         int ns = done;
@@ -272,6 +282,7 @@ class Solver {
         tm.end();
         SolveResult r2;
         solve_core(fd, 2, cplx, n_vec - ns, r2);
+        tail_refined = r2.weak_refined;
         const int k = std::min(n_vec - ns, r2.n_vec);
         for (int j = 0; j < k && ns + j < (int)out.sigma.size(); ++j) out.sigma[ns + j] = r2.sigma[j];
         for (int s = 0; s < 2; ++s) {
@@ -305,6 +316,19 @@ class Solver {
         out.ldv[1] = fields[1].N;
         return;
       }
+    }
+    static const bool one_sided_on = [] { const char* e = std::getenv("XMCA_ONE_SIDED"); return !(e && e[0] == '0'); }();
+    if (n_fields == 2 && one_sided_on && A.N > A.T && fields[1].N > fields[1].T) {
+      // two wide fields: the first one enters through a factor M, M^H M = G_a - its Cholesky factor when that passes the
+      // guards (factor_by_cholesky, solve_one_sided), else its eigen-factor
+      gram(A, cplx, G);
+      CPlanes Fm;
+      if (factor_by_cholesky(G, T, cplx, rows_sum_to_zero(G, T, cplx), Fm) &&
+          solve_one_sided(A, fields[1], cplx, Fm, nullptr, n_vec_req, out, G, true))
+        return;
+      reduce_field_gram(A, cplx, Ra, G, &out.evd_info[0], true);
+      solve_one_sided(A, fields[1], cplx, Ra.Z, Ra.s.get(), n_vec_req, out, G, false);
+      return;
     }
     reduce_field(A, cplx, Ra, G, &out.evd_info[0], n_fields == 2 || n_vec_req != 0);
 
@@ -357,11 +381,6 @@ class Solver {
 
     // ------------------------------- two fields ------------------------------------------------
     const FieldData<TI>& B = fields[1];
-    static const bool one_sided_on = [] { const char* e = std::getenv("XMCA_ONE_SIDED"); return !(e && e[0] == '0'); }();
-    if (one_sided_on && Ra.reduced && B.N > B.T) {
-      solve_one_sided(A, B, cplx, Ra, n_vec_req, out);
-      return;
-    }
     reduce_field(B, cplx, Rb, G, &out.evd_info[1]);
     const int ra = Ra.r, rb = Rb.r;
     const int rank = std::min(ra, rb);
@@ -488,8 +507,12 @@ class Solver {
   //   v_right,m ~ X~b^H (F_a p_m),    v_left,m ~ X~a^H (G_b F_a p_m) = dof C v_right,m     (rows normalised afterwards),
   // which also fixes the shared phase gauge u^H C v = +sigma.
   // -------------------------------------------------------------------------------------------------------------
-  void solve_one_sided(const FieldData<TI>& A, const FieldData<TI>& B, bool cplx, const Reduced& Ra, int n_vec_req, SolveResult& out) {
-    const int T = (int)A.T, ra = Ra.r;
+  // Mf (T x T planes), ms (row scale or null): the factor M = diag(ms) Mf with M^H M = G_a (Ga).  guard: M is a Cholesky
+  // factor on probation - the Gram matrix of the left vectors is checked in time-space coordinates (Thl G_a Thl^H, as in
+  // solve_analytic) and `false` is returned, with nothing usable in `out`, when they are not orthogonal to 1e-6.
+  bool solve_one_sided(const FieldData<TI>& A, const FieldData<TI>& B, bool cplx, const CPlanes& Mf, const double* ms, int n_vec_req,
+                       SolveResult& out, const CPlanes& Ga, bool guard) {
+    const int T = (int)A.T, ra = T;
     const double dof = (double)(T - 1);
     const int rank = ra;                       // = T = min(T, Nx, Ny)
     out.rank = rank;
@@ -498,11 +521,11 @@ class Solver {
     tm.begin("kernel");
     M1.ensure((size_t)ra * T, cplx);
     H.ensure((size_t)ra * ra, cplx);
-    // M1 = (S_a Z_a) G_b ;  H = M1 (S_a Z_a)^H / dof^2
-    cgemm<double>(st, gws, Ra.Z.r(), Ra.Z.i(cplx), T, true, false, Gb.r(), Gb.i(cplx), T, true, false, M1.r(), M1.i(cplx), T, ra, T, T,
-                  1.0, Ra.s.get(), nullptr, false);
-    cgemm<double>(st, gws, M1.r(), M1.i(cplx), T, true, false, Ra.Z.r(), Ra.Z.i(cplx), T, false, true, H.r(), H.i(cplx), ra, ra, ra, T,
-                  1.0 / (dof * dof), nullptr, Ra.s.get(), true);
+    // M1 = M G_b ;  H = M1 M^H / dof^2
+    cgemm<double>(st, gws, Mf.r(), Mf.i(cplx), T, true, false, Gb.r(), Gb.i(cplx), T, true, false, M1.r(), M1.i(cplx), T, ra, T, T,
+                  1.0, ms, nullptr, false);
+    cgemm<double>(st, gws, M1.r(), M1.i(cplx), T, true, false, Mf.r(), Mf.i(cplx), T, false, true, H.r(), H.i(cplx), ra, ra, ra, T,
+                  1.0 / (dof * dof), nullptr, ms, true);
     tm.end();
     const int m = n_vec_req < 0 ? rank : std::min(n_vec_req, rank);
     std::vector<double> lam;
@@ -517,28 +540,80 @@ class Solver {
     out.n_vec = m;
     out.ldv[0] = A.N;
     out.ldv[1] = B.N;
-    if (m == 0) return;
+    if (m == 0) return true;
     tm.begin("backproject");
-    // Th_a[m][t] = conj((F_a p_m)[t]) = ((Ph diag(s_a)) Z_a)[m][t] ;  Th_l = Th_a G_b  (G_b Hermitian)
+    // Th_a[m][t] = conj((M^H p_m)[t]) = ((Ph diag(ms)) Mf)[m][t] ;  Th_l = Th_a G_b  (G_b Hermitian)
     CPlanes Ws, Tha, Thl;
     Ws.ensure((size_t)m * ra, cplx);
     Tha.ensure((size_t)m * T, cplx);
     Thl.ensure((size_t)m * T, cplx);
     XMCA_HIP(hipMemcpyAsync(Ws.r(), Ph.r(), sizeof(double) * (size_t)m * ra, hipMemcpyDeviceToDevice, st));
     if (cplx) XMCA_HIP(hipMemcpyAsync(Ws.im.get(), Ph.im.get(), sizeof(double) * (size_t)m * ra, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(scale_kernel, ew_grid((int64_t)m * ra), dim3(EW_BLOCK), 0, st, Ws.r(), Ws.i(cplx), (int64_t)ra, m, ra, Ra.s.get(),
-                       0, 0);
-    cgemm<double>(st, gws, Ws.r(), Ws.i(cplx), ra, true, false, Ra.Z.r(), Ra.Z.i(cplx), T, true, false, Tha.r(), Tha.i(cplx), T, m, T, ra,
+    if (ms)
+      hipLaunchKernelGGL(scale_kernel, ew_grid((int64_t)m * ra), dim3(EW_BLOCK), 0, st, Ws.r(), Ws.i(cplx), (int64_t)ra, m, ra, ms, 0, 0);
+    cgemm<double>(st, gws, Ws.r(), Ws.i(cplx), ra, true, false, Mf.r(), Mf.i(cplx), T, true, false, Tha.r(), Tha.i(cplx), T, m, T, ra,
                   1.0, nullptr, nullptr, false);
     cgemm<double>(st, gws, Tha.r(), Tha.i(cplx), T, true, false, Gb.r(), Gb.i(cplx), T, true, false, Thl.r(), Thl.i(cplx), T, m, T, T, 1.0,
                   nullptr, nullptr, false);
     XMCA_HIP(hipStreamSynchronize(st));
-    // (the weak modes of this route are refined from the deflated FIELDS, Solver::refine_by_deflation: on spectra graded over
-    //  10 decades the weak block of H - refine_weak_block, enough for the analytic route - stops at ~1e-7 sigma_1 here, because
-    //  the eigen-decomposition of G_a itself carries an absolute error of eps lambda_a1)
+    tm.end();
+    // weak block of H from the rows of Tha / Thl and projection of the weak rows against the strong ones, as in the analytic
+    // route (time-space coordinates: metrics G_a, G_b).  In this route it is trusted down to 1e-5 sigma_1 (on the 10-decade
+    // probe its absolute error is ~7e-12 sigma_1); what lies below is left to refine_by_deflation.
+    refine_weak_block(Tha, Thl, m, T, dof, out, cplx, &Ga, &Gb);
+    if (guard && m > 1) {
+      tm.begin("orthogonality_check");
+      int n_check = 0;                                     // null modes carry arbitrary vectors
+      while (n_check < m && out.sigma[n_check] > 1e-9 * out.sigma[0]) ++n_check;
+      const double worst = coherence(Thl, Ga, m, T, n_check, cplx);
+      tm.end();
+      static const bool trace = std::getenv("XMCA_SOLVE_TRACE") != nullptr;
+      if (trace) std::fprintf(stderr, "[xmca solve] Cholesky factor (time space): left-vector coherence %.3e over %d modes\n", worst, n_check);
+      if (!(worst < 1e-6)) return false;
+    }
+    tm.begin("backproject");
     back_project(B, cplx, Tha.r(), Tha.i(cplx), m, out.Vt[1]);
     back_project(A, cplx, Thl.r(), Thl.i(cplx), m, out.Vt[0]);
     tm.end();
+    return true;
+  }
+
+  // largest |C_ij| / sqrt(C_ii C_jj) over the leading n_check rows of C = E G E^H (E: nv x n rows, G: n x n metric)
+  double coherence(const CPlanes& E, const CPlanes& G, int nv, int n, int n_check, bool cplx) {
+    CPlanes T1, C;
+    DevBuf<double> coh;
+    T1.ensure((size_t)nv * n, cplx);
+    C.ensure((size_t)nv * nv, cplx);
+    cgemm<double>(st, gws, E.r(), E.i(cplx), n, true, false, G.r(), G.i(cplx), n, true, false, T1.r(), T1.i(cplx), n, nv, n, n, 1.0, nullptr,
+                  nullptr, false);
+    cgemm<double>(st, gws, T1.r(), T1.i(cplx), n, true, false, E.r(), E.i(cplx), n, false, true, C.r(), C.i(cplx), nv, nv, nv, n, 1.0,
+                  nullptr, nullptr, false);
+    XMCA_HIP(hipMemsetAsync(coh.ensure(1), 0, sizeof(double), st));
+    hipLaunchKernelGGL(coherence_kernel, dim3(std::min(nv, 1024)), dim3(256), 0, st, C.r(), C.i(cplx), nv, n_check,
+                       reinterpret_cast<unsigned long long*>(coh.get()));
+    double worst = 0.0;
+    XMCA_HIP(hipMemcpyAsync(&worst, coh.get(), sizeof(double), hipMemcpyDeviceToHost, st));
+    XMCA_HIP(hipStreamSynchronize(st));
+    return worst;
+  }
+
+  // true when every row of the Hermitian G sums to (numerically) zero: G 1 = 0, the Gram matrix of column-centered fields
+  bool rows_sum_to_zero(const CPlanes& G, int n, bool cplx) {
+    DevBuf<double> y;
+    std::vector<double> hy((size_t)n);
+    y.ensure((size_t)n);
+    double worst = 0.0, maxdiag = 0.0;
+    for (int pl = 0; pl < (cplx ? 2 : 1); ++pl) {
+      hipLaunchKernelGGL(row_sum_kernel, dim3(n), dim3(256), 0, st, pl ? G.im.get() : G.r(), n, y.get());
+      XMCA_HIP(hipMemcpyAsync(hy.data(), y.get(), sizeof(double) * n, hipMemcpyDeviceToHost, st));
+      XMCA_HIP(hipStreamSynchronize(st));
+      for (int i = 0; i < n; ++i) worst = std::max(worst, std::fabs(hy[i]));
+    }
+    std::vector<double> d((size_t)n);
+    XMCA_HIP(hipMemcpy2DAsync(d.data(), sizeof(double), G.r(), sizeof(double) * (n + 1), sizeof(double), (size_t)n, hipMemcpyDeviceToHost, st));
+    XMCA_HIP(hipStreamSynchronize(st));
+    for (int i = 0; i < n; ++i) maxdiag = std::max(maxdiag, d[i]);
+    return maxdiag > 0.0 && worst < 1e-9 * maxdiag * std::sqrt((double)n);
   }
 
   // -------------------------------------------------------------------------------------------------------------
@@ -685,6 +760,7 @@ class Solver {
   // Ga / Gb: metrics of the left / right coefficient rows (Gy_a, Gy_b) for the projection above, or null
   void refine_weak_block(CPlanes& Er, CPlanes& El, int nv, int m, double dof, SolveResult& out, bool cplx = true,
                          const CPlanes* Ga = nullptr, const CPlanes* Gb = nullptr) {
+    out.weak_refined = false;
     if constexpr (std::is_same<TI, float>::value) return;        // float32 fields: sigma is resolved to 6e-8 sigma_1 at best
     static const double thr = [] { const char* e = std::getenv("XMCA_DEFLATE_BELOW"); return e ? std::atof(e) : 1e-3; }();   // 0: off
     if (thr <= 0.0 || nv <= 1 || !(out.sigma[0] > 0.0)) return;
@@ -808,6 +884,7 @@ class Solver {
     const int m = an.m;
     out.cplx = true;
     out.weak_refined = false;
+    for (EvdInfo& e : out.evd_info) e = EvdInfo();
     out.rank = T;                                   // min(T, N) as the reference reports it (array.py:597)
     const int n_vec = n_vec_req < 0 ? T : std::min(n_vec_req, T);
     const int nv = std::min(n_vec, m);              // modes that can be non-null
@@ -893,22 +970,9 @@ class Solver {
           // along the strong modes that project_out_rows has to remove (2e-8 left on the 10-decade probe, 4e-8 at C3 - the leading
           // modes among themselves, the same with either factor).  Above 1e-6 the factor is not trusted: decompose the field.
           tm.begin("orthogonality_check");
-          CPlanes T1, C;
-          DevBuf<double> coh;
-          T1.ensure((size_t)nv * m, true);
-          C.ensure((size_t)nv * nv, true);
-          cgemm<double>(st, gws, El.r(), El.im.get(), m, true, false, Gya.r(), Gya.im.get(), m, true, false, T1.r(), T1.im.get(), m, nv, m, m,
-                        1.0, nullptr, nullptr, false);
-          cgemm<double>(st, gws, T1.r(), T1.im.get(), m, true, false, El.r(), El.im.get(), m, false, true, C.r(), C.im.get(), nv, nv, nv, m,
-                        1.0, nullptr, nullptr, false);
-          XMCA_HIP(hipMemsetAsync(coh.ensure(1), 0, sizeof(double), st));
           int n_check = 0;                                     // null modes carry arbitrary vectors
           while (n_check < nv && out.sigma[n_check] > 1e-9 * out.sigma[0]) ++n_check;
-          hipLaunchKernelGGL(coherence_kernel, dim3(std::min(nv, 1024)), dim3(256), 0, st, C.r(), C.im.get(), nv, n_check,
-                             reinterpret_cast<unsigned long long*>(coh.get()));
-          double worst = 0.0;
-          XMCA_HIP(hipMemcpyAsync(&worst, coh.get(), sizeof(double), hipMemcpyDeviceToHost, st));
-          XMCA_HIP(hipStreamSynchronize(st));
+          const double worst = coherence(El, Gya, nv, m, n_check, true);
           tm.end();
           static const bool trace = std::getenv("XMCA_SOLVE_TRACE") != nullptr;
           if (trace) std::fprintf(stderr, "[xmca solve] Cholesky factor: left-vector coherence %.3e over %d modes\n", worst, n_check);
