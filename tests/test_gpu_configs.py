@@ -56,7 +56,8 @@ def test_c3_at_full_size_matches_reference():
         G = V[:, sel].conj().T @ V
         assert np.max(np.abs(G - np.eye(2500)[sel])) < 1e-6, key
     info = m._device().solve_info()
-    assert info[0]["sweeps"] == 0 and info[2]["sweeps"] > 0          # no eigen-decomposition of the first field (Cholesky factor)
+    if os.environ.get("XMCA_CHOLESKY_FACTOR", "1") != "0":
+        assert info[0]["sweeps"] == 0 and info[2]["sweeps"] > 0      # no eigen-decomposition of the first field (Cholesky factor)
 
 
 def _check_config(gold, name, cplx, n_rot, power, preprocess):
