@@ -56,6 +56,20 @@ def device_step(h, T, N, n_rot, power, dtype):
     return sig, out
 
 
+def pmc_traffic(kernel, same_workload):
+    """HBM-side bytes per launch of `kernel` from the committed PMC passes (profiles/r02_pmc_c2.json: separate rocprofv3 --pmc
+    runs of `bench.py --steps 1` at the default workload, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950);
+    None when the file is absent or the workload is not the one that was profiled."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_c2.json")
+    if not same_workload or not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            return float(json.load(f)[kernel]["hbm_side_bytes_per_launch_gfx950_corrected"])
+    except (KeyError, ValueError, OSError):
+        return None
+
+
 def launch_ranks(args):
     """--gpus N > 1 outside a launcher: re-run this script as N ranks (one per GPU) and pass rank 0's line through."""
     s = socket.socket()
@@ -177,7 +191,10 @@ def main():
         roofline = {"kernel": "jacobi_fused_round_kernel<%d,real> (v_mfma_f64_16x16x4_f64; one launch per round, %d rounds per sweep)"
                               % (nt, 2 * S - 1),
                     "bound": "mfma", "achieved": tf, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / F64_MFMA_PEAK_TF,
-                    "traffic": None,      # HBM bytes per launch come from separate rocprofv3 --pmc passes: profiles/r02_pmc_*.json
+                    "traffic": pmc_traffic("jacobi_fused_round_kernel<64,false>", (T, N) == (2920, 10000) and nt == 64),
+                    "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at the default workload, "
+                                      "gfx950-corrected, bytes per launch: profiles/r02_pmc_c2.json (scripts/r02_profiles.sh); "
+                                      "null for any other workload",
                     "flops_per_launch": flops_round, "avg_launch_us": us_round, "launches_per_step": round_launches / args.steps,
                     "share_of_step": round_ms / args.steps / ms_per_step,
                     "algorithmic_bytes": bytes_round, "algorithmic_GBs": bytes_round / us_round / 1e3,
