@@ -171,6 +171,11 @@ int xmca_surrogate(xmca_handle* h, int64_t n, uint64_t seed, uint32_t run, uint3
 int xmca_get_timings(xmca_handle* h, char* names, int names_len, double* ms, int max_n);
 int xmca_reset_timings(xmca_handle* h);
 
+/* Batched complex DFT used by the analytic-signal path (csrc/fft.h), host in / host out, for the parity tests:
+ * out[b][k] = sum_t in[b][t] exp(sign 2 pi i k t / n), b < batch, k < n; planes of batch x n float64, in_im may be NULL.
+ * Returns XMCA_ERR_UNSUPPORTED when n has a prime factor above 7 or exceeds 5120 (the solver then uses GEMMs). */
+int xmca_fft(xmca_handle* h, const double* in_re, const double* in_im, int batch, int n, int sign, double* out_re, double* out_im);
+
 /* Device memory kept by the handle.  The solver's temporaries come from a per-handle pool (hipFree waits for the whole
  * device): blocks are kept after a call, up to XMCA_POOL_LIMIT_GB (default 32) in total.
  * xmca_pool_bytes reports what is held right now (lanes of rule_n included), xmca_trim_pool gives it back to the driver. */

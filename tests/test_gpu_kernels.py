@@ -255,3 +255,21 @@ def test_cholesky_semidefinite_needs_the_shift(hip):
     assert np.max(np.abs(R.T @ R - A)) / np.max(np.abs(A)) < 1e-12
     _, ok = hip.cholesky(-A)                              # not positive: reported, no exception
     assert not ok
+
+
+@pytest.mark.parametrize("n", [2, 3, 4, 5, 7, 8, 12, 60, 150, 343, 1000, 2501 - 1, 4200, 5000, 5120])
+def test_fft_matches_numpy(hip, n):
+    """csrc/fft.h (Stockham, radices 4/2/3/5/7, one workgroup per transform in LDS) against numpy.fft in both directions,
+    complex and real input; the analytic-signal path uses it for the Fourier reduction of the Gram matrix (T = 5000: 2^3 5^4)."""
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((5, n)) + 1j * rng.standard_normal((5, n))
+    scale = np.sqrt(n)
+    assert np.max(np.abs(hip.fft(x, -1) - np.fft.fft(x, axis=1))) < 1e-13 * scale * np.abs(x).max() * np.log2(n + 1)
+    assert np.max(np.abs(hip.fft(x, +1) - np.fft.ifft(x, axis=1) * n)) < 1e-13 * scale * np.abs(x).max() * np.log2(n + 1)
+    assert np.max(np.abs(hip.fft(x.real, -1) - np.fft.fft(x.real, axis=1))) < 1e-13 * scale * np.log2(n + 1) * 5
+
+
+def test_fft_refuses_lengths_it_cannot_factor(hip):
+    for n in (11, 2 * 31, 2920, 5121 * 2):
+        with pytest.raises(Exception):
+            hip.fft(np.ones((1, n)))

@@ -35,7 +35,8 @@ def _oracle_run(hip, T, widths, seed, run, cplx, rot):
 @pytest.mark.parametrize("T,widths,cplx,rot", [
     (40, (24, 18), False, None),            # both fields narrower than T (primal route)
     (60, (300, 200), False, None),          # both wider (values-only Cholesky route)
-    (60, (300, 200), True, None),           # analytic-signal subspace
+    (60, (300, 200), True, None),           # analytic-signal subspace (T = 2^2 3 5: Fourier reduction by FFT)
+    (62, (300, 200), True, None),           # ... T = 2 x 31: by products with the explicit Fourier vectors
     (60, (300,), False, None),              # EOF
     (48, (120, 30), True, None),            # mixed widths, complex
     (60, (300, 200), False, (6, 1)),        # rotated: Varimax

@@ -55,6 +55,7 @@ SIGNATURES = {
     "xmca_surrogate": (_c_int, [_vp, _c_i64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _vp]),
     "xmca_get_timings": (_c_int, [_vp, ctypes.c_char_p, _c_int, _vp, _c_int]),
     "xmca_reset_timings": (_c_int, [_vp]),
+    "xmca_fft": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, _vp, _vp]),
     "xmca_pool_bytes": (_c_int, [_vp, ctypes.POINTER(ctypes.c_int64)]),
     "xmca_trim_pool": (_c_int, [_vp]),
     "xmca_gemm": (_c_int, [_vp, _vp, _c_i64, _c_int, _vp, _c_i64, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_dbl,
@@ -398,6 +399,15 @@ class Handle:
 
     def reset_timings(self):
         self._check(self._lib.xmca_reset_timings(self._h))
+
+    def fft(self, x, sign=-1):
+        """Batched DFT along the last axis of a 2-D array (rows), numpy.fft.fft convention for sign = -1 (csrc/fft.h)."""
+        x = np.asarray(x)
+        re = np.ascontiguousarray(x.real, dtype=np.float64)
+        im = np.ascontiguousarray(x.imag, dtype=np.float64) if np.iscomplexobj(x) else None
+        out_r, out_i = np.empty_like(re), np.empty_like(re)
+        self._check(self._lib.xmca_fft(self._h, _ptr(re), _ptr(im), re.shape[0], re.shape[1], int(sign), _ptr(out_r), _ptr(out_i)))
+        return out_r + 1j * out_i
 
     def pool_bytes(self):
         """device memory the handle keeps for re-use (solver temporaries; include/xmca_hip.h xmca_pool_bytes)"""

@@ -1,0 +1,146 @@
+// Batched complex DFTs of length n <= 5120 = 2^a 3^b 5^c 7^d, one workgroup per transform, the whole transform in LDS
+// (Stockham autosort: no bit reversal, two ping-pong buffers of n complex f64 = 32 n bytes).  gfx950 only.
+//
+// Used for the Fourier reduction of the analytic-signal path, Gy = D Phi^H (X X^T) Phi D (solver.h analytic_gram): as two
+// GEMMs against the explicit Fourier vectors that is 3.75e11 flop at T = 5000 (8 ms per field); as a 2-D DFT of the T x T
+// Gram matrix it is 2 x 5000 transforms of 5000 points - memory-bound on 200 MB.
+#pragma once
+#include "common.h"
+
+namespace xmca {
+
+struct FftPlan {
+  int n = 0;
+  int n_stages = 0;
+  int radix[24] = {0};
+};
+
+// false when n has a prime factor above 7 or does not fit the LDS of a workgroup
+static inline bool fft_plan(int n, FftPlan& p) {
+  p.n = n;
+  p.n_stages = 0;
+  if (n < 2 || (size_t)n * 32 > (size_t)160 * 1024) return false;
+  int rest = n;
+  for (int r : {4, 2, 3, 5, 7}) {
+    while (rest % r == 0 && p.n_stages < 24) {
+      p.radix[p.n_stages++] = r;
+      rest /= r;
+    }
+  }
+  return rest == 1;
+}
+
+template <int R>
+struct FftRoots;   // cos / sin of 2 pi k / R
+template <> struct FftRoots<2> { static constexpr double c[2] = {1.0, -1.0}; static constexpr double s[2] = {0.0, 0.0}; };
+template <> struct FftRoots<3> {
+  static constexpr double c[3] = {1.0, -0.5, -0.5};
+  static constexpr double s[3] = {0.0, 0.86602540378443864676, -0.86602540378443864676};
+};
+template <> struct FftRoots<4> { static constexpr double c[4] = {1.0, 0.0, -1.0, 0.0}; static constexpr double s[4] = {0.0, 1.0, 0.0, -1.0}; };
+template <> struct FftRoots<5> {
+  static constexpr double c[5] = {1.0, 0.30901699437494742410, -0.80901699437494742410, -0.80901699437494742410, 0.30901699437494742410};
+  static constexpr double s[5] = {0.0, 0.95105651629515357212, 0.58778525229247312917, -0.58778525229247312917, -0.95105651629515357212};
+};
+template <> struct FftRoots<7> {
+  static constexpr double c[7] = {1.0, 0.62348980185873353053, -0.22252093395631440429, -0.90096886790241912624,
+                                  -0.90096886790241912624, -0.22252093395631440429, 0.62348980185873353053};
+  static constexpr double s[7] = {0.0, 0.78183148246802980871, 0.97492791218182360702, 0.43388373911755812048,
+                                  -0.43388373911755812048, -0.97492791218182360702, -0.78183148246802980871};
+};
+
+// one Stockham stage of radix R on n points: Ns = product of the radices of the stages before it
+template <int R>
+__device__ __forceinline__ void fft_stage(const double* __restrict__ ar, const double* __restrict__ ai, double* __restrict__ br,
+                                          double* __restrict__ bi, const int n, const int Ns, const double sign) {
+  const int nr = n / R;
+  for (int j = threadIdx.x; j < nr; j += blockDim.x) {
+    const int k = j % Ns;
+    const double ang = 2.0 * (double)k / (double)(Ns * R);     // in units of pi
+    double vr[R], vi[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const double xr = ar[j + r * nr], xi = ai[j + r * nr];
+      if (r == 0) { vr[0] = xr; vi[0] = xi; continue; }
+      double sn, cs;
+      sincospi(ang * (double)r, &sn, &cs);
+      sn *= sign;
+      vr[r] = xr * cs - xi * sn;
+      vi[r] = xr * sn + xi * cs;
+    }
+    const int j0 = (j - k) * R + k;
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      double yr = vr[0], yi = vi[0];
+#pragma unroll
+      for (int r = 1; r < R; ++r) {
+        const double c = FftRoots<R>::c[(q * r) % R], s = sign * FftRoots<R>::s[(q * r) % R];
+        yr += vr[r] * c - vi[r] * s;
+        yi += vr[r] * s + vi[r] * c;
+      }
+      br[j0 + q * Ns] = yr;
+      bi[j0 + q * Ns] = yi;
+    }
+  }
+}
+
+// out[b][k] = sa[k] sb[b] scale * sum_{t < n_in} x[b][t] exp(sign 2 pi i k t / n),  k < n_keep, for the transforms b = blockIdx.x,
+// with x = in (in_i may be null: real input) or sin[t] * conj(in) when conj_in is set (sin may be null).
+// Element (b, t) of the input is at b * in_bs + t * in_es, of the output at b * out_bs + k * out_es.
+__global__ __launch_bounds__(256) void fft_batch_kernel(const double* __restrict__ in_r, const double* __restrict__ in_i, int64_t in_bs,
+                                                        int64_t in_es, int n_in, int conj_in, const double* __restrict__ sin_,
+                                                        FftPlan plan, double sign, double* __restrict__ out_r,
+                                                        double* __restrict__ out_i, int64_t out_bs, int64_t out_es, int n_keep,
+                                                        const double* __restrict__ sa, const double* __restrict__ sb, double scale) {
+  extern __shared__ __attribute__((aligned(16))) char fft_smem[];
+  const int n = plan.n;
+  double* ar = reinterpret_cast<double*>(fft_smem);
+  double* ai = ar + n;
+  double* br = ai + n;
+  double* bi = br + n;
+  const int64_t b = blockIdx.x;
+  for (int t = threadIdx.x; t < n; t += blockDim.x) {
+    const double f = t < n_in ? (sin_ ? sin_[t] : 1.0) : 0.0;
+    ar[t] = t < n_in ? f * in_r[b * in_bs + t * in_es] : 0.0;
+    ai[t] = (t < n_in && in_i) ? (conj_in ? -f : f) * in_i[b * in_bs + t * in_es] : 0.0;
+  }
+  __syncthreads();
+  int Ns = 1;
+  for (int st = 0; st < plan.n_stages; ++st) {
+    const int R = plan.radix[st];
+    switch (R) {
+      case 2: fft_stage<2>(ar, ai, br, bi, n, Ns, sign); break;
+      case 3: fft_stage<3>(ar, ai, br, bi, n, Ns, sign); break;
+      case 4: fft_stage<4>(ar, ai, br, bi, n, Ns, sign); break;
+      case 5: fft_stage<5>(ar, ai, br, bi, n, Ns, sign); break;
+      default: fft_stage<7>(ar, ai, br, bi, n, Ns, sign); break;
+    }
+    Ns *= R;
+    __syncthreads();
+    { double* t = ar; ar = br; br = t; }
+    { double* t = ai; ai = bi; bi = t; }
+  }
+  const double fb = scale * (sb ? sb[b] : 1.0);
+  for (int k = threadIdx.x; k < n_keep; k += blockDim.x) {
+    const double f = fb * (sa ? sa[k] : 1.0);
+    out_r[b * out_bs + k * out_es] = ar[k] * f;
+    out_i[b * out_bs + k * out_es] = ai[k] * f;
+  }
+}
+
+inline void fft_batch(hipStream_t st, const FftPlan& plan, int batch, const double* in_r, const double* in_i, int64_t in_bs, int64_t in_es,
+                      double sign, double* out_r, double* out_i, int64_t out_bs, int64_t out_es, int n_keep, const double* sa,
+                      const double* sb, double scale, int n_in = -1, bool conj_in = false, const double* sin_ = nullptr) {
+  if (n_in < 0) n_in = plan.n;
+  const size_t smem = (size_t)plan.n * 32;
+  static size_t attr_set = 0;
+  if (smem > attr_set) {
+    XMCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fft_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_set = smem;
+  }
+  hipLaunchKernelGGL(fft_batch_kernel, dim3(batch), dim3(256), smem, st, in_r, in_i, in_bs, in_es, n_in, conj_in ? 1 : 0, sin_, plan, sign,
+                     out_r, out_i, out_bs, out_es, n_keep, sa, sb, scale);
+  XMCA_HIP(hipGetLastError());
+}
+
+}  // namespace xmca

@@ -138,6 +138,24 @@ __global__ void row_sum_kernel(const double* __restrict__ A, int n, double* __re
   if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// exactly Hermitian from nearly Hermitian: (G + G^H) / 2 on the planes of an n x n matrix (imaginary diagonal -> 0)
+__global__ void hermitize_kernel(double* __restrict__ Gr, double* __restrict__ Gi, int n) {
+  const int64_t total = (int64_t)n * n;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(idx / n), j = (int)(idx % n);
+    if (j < i) continue;
+    const int64_t a = (int64_t)i * n + j, b = (int64_t)j * n + i;
+    const double re = 0.5 * (Gr[a] + Gr[b]);
+    Gr[a] = re;
+    Gr[b] = re;
+    if (Gi) {
+      const double im = i == j ? 0.0 : 0.5 * (Gi[a] - Gi[b]);
+      Gi[a] = im;
+      Gi[b] = -im;
+    }
+  }
+}
+
 // x[i] += v
 __global__ void add_const_kernel(double* __restrict__ x, int64_t n, double v) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] += v;

@@ -9,6 +9,7 @@
 #include "common.h"
 #include "gemm.h"
 #include "cholesky.h"
+#include "fft.h"
 #include "jacobi.h"
 #include "kernels.h"
 #include "rotate.h"
@@ -660,11 +661,22 @@ class Solver {
     }
     tm.end();
     tm.begin("fourier_reduce");
-    // P1 = G Phi ;  Gy = D (Phi^H P1) D
-    cgemm<double>(st, gws, G.get(), nullptr, T, true, false, an.Phi.r(), an.Phi.im.get(), m, true, false, P1.r(), P1.im.get(), m, T, m, T,
-                  1.0, nullptr, nullptr, false);
-    cgemm<double>(st, gws, an.Phi.r(), an.Phi.im.get(), m, false, true, P1.r(), P1.im.get(), m, true, false, Gy.r(), Gy.im.get(), m, m, m,
-                  T, 1.0, an.h.get(), an.h.get(), true);
+    // Gy[k][l] = h_k h_l / T  sum_s sum_t exp(-2 pi i k s / T) G[s][t] exp(+2 pi i l t / T): a 2-D DFT of G of which the
+    // m x m corner is kept (fft.h: T transforms along the rows, m along the columns, each in the LDS of one workgroup) when T
+    // factors into 2, 3, 5, 7 and fits; otherwise two products with the explicit Fourier vectors: P1 = G Phi, Gy = D (Phi^H P1) D
+    static const bool fft_on = [] { const char* e = std::getenv("XMCA_FFT"); return !(e && e[0] == '0'); }();
+    FftPlan plan;
+    if (fft_on && fft_plan(T, plan)) {
+      fft_batch(st, plan, T, G.get(), nullptr, T, 1, +1.0, P1.r(), P1.im.get(), m, 1, m, nullptr, nullptr, 1.0);
+      fft_batch(st, plan, m, P1.r(), P1.im.get(), 1, m, -1.0, Gy.r(), Gy.im.get(), 1, m, m, an.h.get(), an.h.get(), 1.0 / (double)T);
+      hipLaunchKernelGGL(hermitize_kernel, ew_grid((int64_t)m * m), dim3(EW_BLOCK), 0, st, Gy.r(), Gy.im.get(), m);
+      XMCA_HIP(hipGetLastError());
+    } else {
+      cgemm<double>(st, gws, G.get(), nullptr, T, true, false, an.Phi.r(), an.Phi.im.get(), m, true, false, P1.r(), P1.im.get(), m, T, m, T,
+                    1.0, nullptr, nullptr, false);
+      cgemm<double>(st, gws, an.Phi.r(), an.Phi.im.get(), m, false, true, P1.r(), P1.im.get(), m, true, false, Gy.r(), Gy.im.get(), m, m, m,
+                    T, 1.0, an.h.get(), an.h.get(), true);
+    }
     tm.end();
     XMCA_HIP(hipStreamSynchronize(st));     // G, P1 are released on return
   }
@@ -697,15 +709,23 @@ class Solver {
     XMCA_HIP(hipMemsetAsync(Vt.im.get(), 0, sizeof(double) * (size_t)rows_total * f.N, st));
     if (nv <= 0) return;
     CPlanes Es, Bt;
-    Es.ensure((size_t)nv * m, true);
     Bt.ensure((size_t)nv * T, true);
-    XMCA_HIP(hipMemcpyAsync(Es.r(), Er, sizeof(double) * (size_t)nv * m, hipMemcpyDeviceToDevice, st));
-    XMCA_HIP(hipMemcpyAsync(Es.im.get(), Ei, sizeof(double) * (size_t)nv * m, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(scale_kernel, ew_grid((int64_t)nv * m), dim3(EW_BLOCK), 0, st, Es.r(), Es.im.get(), (int64_t)m, nv, m, an.h.get(),
-                       0, 0);
-    // Bt = conj(Es) Phi^T      (nv x T)
-    cgemm<double>(st, gws, Es.r(), Es.im.get(), m, true, true, an.Phi.r(), an.Phi.im.get(), m, false, false, Bt.r(), Bt.im.get(), T, nv, T,
-                  m, 1.0, nullptr, nullptr, false);
+    // Bt[i][t] = sum_k h_k conj(E[i][k]) exp(2 pi i k t / T) / sqrt(T)      (nv x T): nv zero-padded DFTs of length T, or
+    // Bt = conj(E D) Phi^T as a product with the explicit Fourier vectors
+    static const bool fft_on = [] { const char* e = std::getenv("XMCA_FFT"); return !(e && e[0] == '0'); }();
+    FftPlan plan;
+    if (fft_on && fft_plan(T, plan)) {
+      fft_batch(st, plan, nv, Er, Ei, m, 1, +1.0, Bt.r(), Bt.im.get(), T, 1, T, nullptr, nullptr, 1.0 / std::sqrt((double)T), m, true,
+                an.h.get());
+    } else {
+      Es.ensure((size_t)nv * m, true);
+      XMCA_HIP(hipMemcpyAsync(Es.r(), Er, sizeof(double) * (size_t)nv * m, hipMemcpyDeviceToDevice, st));
+      XMCA_HIP(hipMemcpyAsync(Es.im.get(), Ei, sizeof(double) * (size_t)nv * m, hipMemcpyDeviceToDevice, st));
+      hipLaunchKernelGGL(scale_kernel, ew_grid((int64_t)nv * m), dim3(EW_BLOCK), 0, st, Es.r(), Es.im.get(), (int64_t)m, nv, m, an.h.get(),
+                         0, 0);
+      cgemm<double>(st, gws, Es.r(), Es.im.get(), m, true, true, an.Phi.r(), an.Phi.im.get(), m, false, false, Bt.r(), Bt.im.get(), T, nv, T,
+                    m, 1.0, nullptr, nullptr, false);
+    }
     Narrow<TI> bt;
     bt.from(st, Bt.r(), Bt.im.get(), (int64_t)nv * T);
     // Vt = Bt X  (complex x real field)

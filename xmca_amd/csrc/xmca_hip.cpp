@@ -1015,6 +1015,23 @@ int xmca_reset_timings(xmca_handle* h) {
   return XMCA_OK;
 }
 
+int xmca_fft(xmca_handle* h, const double* in_re, const double* in_im, int batch, int n, int sign, double* out_re, double* out_im) {
+  API_BEGIN(h)
+  XMCA_CHECK(in_re && out_re && out_im && batch >= 1 && n >= 2 && (sign == 1 || sign == -1), XMCA_ERR_INVALID, "fft: bad arguments");
+  FftPlan plan;
+  XMCA_CHECK(fft_plan(n, plan), XMCA_ERR_UNSUPPORTED, "fft: length must factor into 2, 3, 5, 7 and be at most 5120");
+  const size_t cnt = (size_t)batch * n;
+  DevBuf<double> ir, ii, orr, oi;
+  XMCA_HIP(hipMemcpyAsync(ir.ensure(cnt), in_re, sizeof(double) * cnt, hipMemcpyHostToDevice, h->st));
+  if (in_im) XMCA_HIP(hipMemcpyAsync(ii.ensure(cnt), in_im, sizeof(double) * cnt, hipMemcpyHostToDevice, h->st));
+  fft_batch(h->st, plan, batch, ir.get(), in_im ? ii.get() : nullptr, n, 1, (double)sign, orr.ensure(cnt), oi.ensure(cnt), n, 1, n, nullptr,
+            nullptr, 1.0);
+  XMCA_HIP(hipMemcpyAsync(out_re, orr.get(), sizeof(double) * cnt, hipMemcpyDeviceToHost, h->st));
+  XMCA_HIP(hipMemcpyAsync(out_im, oi.get(), sizeof(double) * cnt, hipMemcpyDeviceToHost, h->st));
+  XMCA_HIP(hipStreamSynchronize(h->st));
+  API_END(h)
+}
+
 int xmca_pool_bytes(xmca_handle* h, int64_t* held_bytes) {
   if (!h || !held_bytes) return XMCA_ERR_INVALID;
   size_t total = 0;
