@@ -41,7 +41,7 @@ typedef struct xmca_handle xmca_handle;
 /* library / device management ------------------------------------------------------------------------- */
 const char* xmca_version(void);
 /* Number of this header's ABI (XMCA_ABI_VERSION): the binding refuses a library built from another revision. */
-#define XMCA_ABI_VERSION 4
+#define XMCA_ABI_VERSION 5
 int xmca_abi_version(void);
 int xmca_device_count(void);
 int xmca_create(int device, xmca_handle** out);

@@ -73,7 +73,7 @@ def library_path():
     return _build.LIB
 
 
-ABI_VERSION = 4          # bumped whenever a signature of include/xmca_hip.h changes; checked against xmca_abi_version()
+ABI_VERSION = 5          # bumped whenever a signature of include/xmca_hip.h changes; checked against xmca_abi_version()
 
 
 def load_library():
