@@ -88,19 +88,32 @@ __global__ void add_diag_kernel(double* __restrict__ G, int64_t ld, int n, doubl
 }
 
 // largest |C_ij| / sqrt(C_ii C_jj), i != j, of an n x n Hermitian Gram matrix with a positive diagonal (rows with a zero
-// diagonal - null modes - are skipped): how far a set of vectors is from orthogonal.  One row per workgroup (grid-stride).
+// diagonal - null modes - are skipped): how far a set of vectors is from orthogonal.  One row per workgroup (grid-stride);
+// row_worst[i] (optional) = the same over j < i only.
 __global__ void coherence_kernel(const double* __restrict__ Cr, const double* __restrict__ Ci, int n, int n_check,
-                                 unsigned long long* __restrict__ out) {
+                                 unsigned long long* __restrict__ out, double* __restrict__ row_worst) {
+  __shared__ double red[4];
   double worst = 0.0;
   for (int i = blockIdx.x; i < n_check; i += gridDim.x) {      // the leading n_check rows / columns of the n x n matrix
     const double dii = Cr[(int64_t)i * n + i];
-    if (!(dii > 0.0)) continue;
-    for (int j = threadIdx.x; j < n_check; j += blockDim.x) {
-      const double djj = Cr[(int64_t)j * n + j];
-      if (j == i || !(djj > 0.0)) continue;
-      const double re = Cr[(int64_t)i * n + j], im = Ci ? Ci[(int64_t)i * n + j] : 0.0;
-      const double c = sqrt((re * re + im * im) / (dii * djj));
-      worst = c > worst || !(c == c) ? (c == c ? c : HUGE_VAL) : worst;
+    double mine = 0.0;                                         // row i against the rows before it (the stronger modes)
+    if (dii > 0.0) {
+      for (int j = threadIdx.x; j < n_check; j += blockDim.x) {
+        const double djj = Cr[(int64_t)j * n + j];
+        if (j == i || !(djj > 0.0)) continue;
+        const double re = Cr[(int64_t)i * n + j], im = Ci ? Ci[(int64_t)i * n + j] : 0.0;
+        double c = sqrt((re * re + im * im) / (dii * djj));
+        if (!(c == c)) c = HUGE_VAL;
+        worst = fmax(worst, c);
+        if (j < i) mine = fmax(mine, c);
+      }
+    }
+    if (row_worst) {
+      for (int o = 32; o > 0; o >>= 1) mine = fmax(mine, __shfl_xor(mine, o));
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mine;
+      __syncthreads();
+      if (threadIdx.x == 0) row_worst[i] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
     }
   }
   for (int o = 32; o > 0; o >>= 1) worst = fmax(worst, __shfl_xor(worst, o));

@@ -112,6 +112,7 @@ struct SolveResult {
   int64_t ldv[2] = {0, 0};
   bool cplx = false;
   bool weak_refined = false;          // the route refined its weak modes itself (Solver::refine_weak_block)
+  int consistent = 0;                 // leading modes whose sigma passed the route's own consistency check (solve_one_sided)
   EvdInfo evd_info[3];
 };
 
@@ -188,6 +189,7 @@ class Solver {
   // n_vec < 0: all modes
   void solve(const FieldData<TI>* fields, int n_fields, bool cplx, int n_vec_req, SolveResult& out) {
     out.weak_refined = false;            // (the caller may hand in the result object of an earlier solve)
+    out.consistent = 0;
     for (EvdInfo& e : out.evd_info) e = EvdInfo();
     solve_core(fields, n_fields, cplx, n_vec_req, out);
     if (n_fields == 2) refine_by_deflation(fields, cplx, out);
@@ -234,12 +236,13 @@ class Solver {
       const int T = (int)fields[0].T;
       int done = 0;
       bool tail_refined = out.weak_refined;      // the solve that produced the current tail refined its weak block itself:
+      int tail_consistent = out.weak_refined ? out.consistent : 0;   // ... and checked this many of its leading modes
       for (int level = 0; level < 3; ++level) {  // its modes are good down to 1e-5 of its top instead of 1e-3
         const double thr = tail_refined ? std::min(thr_plain, 1e-5) : thr_plain;
         const double top = out.sigma[done];
         if (!(top > 0.0)) break;
         int ns = done;
-        while (ns < n_vec && out.sigma[ns] >= thr * top) ++ns;
+        while (ns < n_vec && (out.sigma[ns] >= thr * top || ns - done < tail_consistent)) ++ns;
         if (ns >= n_vec || ns == done) break;                            // nothing with vectors lies below
         if (!(out.sigma[ns] > 1e-13 * out.sigma[0])) break;              // what is left is null
         tm.begin("deflate");
@@ -284,6 +287,7 @@ class Solver {
         SolveResult r2;
         solve_core(fd, 2, cplx, n_vec - ns, r2);
         tail_refined = r2.weak_refined;
+        tail_consistent = r2.weak_refined ? r2.consistent : 0;
         const int k = std::min(n_vec - ns, r2.n_vec);
         for (int j = 0; j < k && ns + j < (int)out.sigma.size(); ++j) out.sigma[ns + j] = r2.sigma[j];
         for (int s = 0; s < 2; ++s) {
@@ -562,15 +566,41 @@ class Solver {
     // route (time-space coordinates: metrics G_a, G_b).  In this route it is trusted down to 1e-5 sigma_1 (on the 10-decade
     // probe its absolute error is ~7e-12 sigma_1); what lies below is left to refine_by_deflation.
     refine_weak_block(Tha, Thl, m, T, dof, out, cplx, &Ga, &Gb);
-    if (guard && m > 1) {
+    out.consistent = 0;
+    if (m > 1) {
+      // C = Thl G_a Thl^H (two products, 10 ms at T = 5000).  Off the diagonal: the Gram matrix of the left vectors (guard of
+      // the Cholesky factor).  On the diagonal: with g = G_b q, g^H G_a g = mu g^H q = mu^2 for an eigenpair of G_a G_b, a
+      // Rayleigh quotient of the pencil (G_b G_a G_b, G_b) that uses G_a itself and not its factor - second order in the
+      // vector's error, so C_ii / mu_i^2 - 1 shows what the factor's absolute error eps lambda_a1 did to sigma_i^2.  The
+      // leading modes that agree to 1e-6 need no second solve (refine_by_deflation): for fields whose weak modes are noise
+      // against noise that is all of them (real C3: down to 1e-8 sigma_1), for variance spectra graded over 10 decades it
+      // stops where the weak block stops being good.
       tm.begin("orthogonality_check");
       int n_check = 0;                                     // null modes carry arbitrary vectors
       while (n_check < m && out.sigma[n_check] > 1e-9 * out.sigma[0]) ++n_check;
-      const double worst = coherence(Thl, Ga, m, T, n_check, cplx);
+      std::vector<double> cdiag, crow;
+      const double worst = coherence(Thl, Ga, m, T, n_check, cplx, &cdiag, &crow);
       tm.end();
+      int ok = 0;
+      double worst_c = 0.0;
+      for (; ok < m; ++ok) {
+        const double mu = out.sigma[ok] * out.sigma[ok] * dof * dof;
+        if (!(out.sigma[ok] > 1e-11 * out.sigma[0])) break;
+        const double dev = std::fabs(cdiag[ok] / (mu * mu) - 1.0);
+        if (!(dev < 1e-6) || !(crow[ok] < 1e-6)) break;       // ... and its left vector must be orthogonal to the stronger ones
+        worst_c = std::max(worst_c, dev);
+      }
+      out.consistent = ok;
       static const bool trace = std::getenv("XMCA_SOLVE_TRACE") != nullptr;
-      if (trace) std::fprintf(stderr, "[xmca solve] Cholesky factor (time space): left-vector coherence %.3e over %d modes\n", worst, n_check);
-      if (!(worst < 1e-6)) return false;
+      if (trace)
+        std::fprintf(stderr, "[xmca solve] one-sided (time space): left-vector coherence %.3e over %d modes; sigma consistent (%.1e) for the "
+                             "leading %d of %d modes, sigma there %.2e sigma_1\n", worst, n_check, worst_c, ok, m,
+                     ok > 0 ? out.sigma[ok - 1] / out.sigma[0] : 1.0);
+      // (guard of the Cholesky factor: over the modes that will be kept from this solve - what lies behind them is solved again)
+      double worst_kept = 0.0;
+      for (int i = 0; i < ok; ++i) worst_kept = std::max(worst_kept, crow[i]);
+      if (guard && !((ok == n_check ? worst : worst_kept) < 1e-6)) return false;
+      if (guard && ok < std::min(n_check, 2)) return false;
     }
     tm.begin("backproject");
     back_project(B, cplx, Tha.r(), Tha.i(cplx), m, out.Vt[1]);
@@ -580,9 +610,13 @@ class Solver {
   }
 
   // largest |C_ij| / sqrt(C_ii C_jj) over the leading n_check rows of C = E G E^H (E: nv x n rows, G: n x n metric)
-  double coherence(const CPlanes& E, const CPlanes& G, int nv, int n, int n_check, bool cplx) {
+  // diag != null: the diagonal of C (nv values) on the host
+  // row_worst != null: per row, the worst coherence with any EARLIER row
+  double coherence(const CPlanes& E, const CPlanes& G, int nv, int n, int n_check, bool cplx, std::vector<double>* diag = nullptr,
+                   std::vector<double>* row_worst = nullptr) {
     CPlanes T1, C;
-    DevBuf<double> coh;
+    DevBuf<double> coh, rw;
+    if (row_worst) XMCA_HIP(hipMemsetAsync(rw.ensure((size_t)nv), 0, sizeof(double) * nv, st));
     T1.ensure((size_t)nv * n, cplx);
     C.ensure((size_t)nv * nv, cplx);
     cgemm<double>(st, gws, E.r(), E.i(cplx), n, true, false, G.r(), G.i(cplx), n, true, false, T1.r(), T1.i(cplx), n, nv, n, n, 1.0, nullptr,
@@ -591,9 +625,18 @@ class Solver {
                   nullptr, nullptr, false);
     XMCA_HIP(hipMemsetAsync(coh.ensure(1), 0, sizeof(double), st));
     hipLaunchKernelGGL(coherence_kernel, dim3(std::min(nv, 1024)), dim3(256), 0, st, C.r(), C.i(cplx), nv, n_check,
-                       reinterpret_cast<unsigned long long*>(coh.get()));
+                       reinterpret_cast<unsigned long long*>(coh.get()), row_worst ? rw.get() : nullptr);
     double worst = 0.0;
     XMCA_HIP(hipMemcpyAsync(&worst, coh.get(), sizeof(double), hipMemcpyDeviceToHost, st));
+    if (row_worst) {
+      row_worst->resize((size_t)nv);
+      XMCA_HIP(hipMemcpyAsync(row_worst->data(), rw.get(), sizeof(double) * nv, hipMemcpyDeviceToHost, st));
+    }
+    if (diag) {
+      diag->resize((size_t)nv);
+      XMCA_HIP(hipMemcpy2DAsync(diag->data(), sizeof(double), C.r(), sizeof(double) * (nv + 1), sizeof(double), (size_t)nv,
+                                hipMemcpyDeviceToHost, st));
+    }
     XMCA_HIP(hipStreamSynchronize(st));
     return worst;
   }
