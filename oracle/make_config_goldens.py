@@ -34,6 +34,7 @@ CONFIGS = [  # name, complexify, n_rot, power, modes of V stored, row stride of 
     ("c3_reduced", True, 20, 4, 20, 1),
     ("c5_scaled", False, 10, 1, 10, 2),
     ("c3_full", True, 20, 4, 20, 8),          # ~6 minutes and ~15 GB on 8 cores; written to config_c3_full.npz
+    ("c3_real_full", False, 20, 2, 20, 8),    # the same fields without complexify (general two-field route); config_c3_real_full.npz
 ]
 
 BOOT = [  # tag, input, single field, complexify, rotation, kwargs  (tests/test_gpu_mca.py bootstrapping cases)
@@ -111,17 +112,19 @@ def main():
     if not only or "configs" in only:
         out = {}
         for name, cplx, n_rot, power, n_vec, stride in CONFIGS:
-            if name == "c3_full":
+            if name in ("c3_full", "c3_real_full"):
                 continue
             for k, v in config_case(MCA, name, cplx, n_rot, power, n_vec, stride).items():
                 out[name + "__" + k] = v
         dst = os.path.join(OUT, "config_cases.npz")
         np.savez_compressed(dst, **out)
         print("wrote %s (%.2f MB)" % (dst, os.path.getsize(dst) / 1e6))
-    if "c3_full" in only:
-        name, cplx, n_rot, power, n_vec, stride = CONFIGS[-1]
+    for big in ("c3_full", "c3_real_full"):
+        if big not in only:
+            continue
+        name, cplx, n_rot, power, n_vec, stride = [c for c in CONFIGS if c[0] == big][0]
         out = {name + "__" + k: v for k, v in config_case(MCA, name, cplx, n_rot, power, n_vec, stride, pin_oracle=False, pcs_stride=5).items()}
-        dst = os.path.join(OUT, "config_c3_full.npz")
+        dst = os.path.join(OUT, "config_%s.npz" % name)
         np.savez_compressed(dst, **out)
         print("wrote %s (%.2f MB)" % (dst, os.path.getsize(dst) / 1e6))
     if not only or "bootstrap" in only:

@@ -131,6 +131,8 @@ def make_input(name):
         return (gen_A(),)
     if name == "c3_reduced":         # BASELINE configs[2] at T = 1000 x (4000, 3000), geometric amplitudes
         return gen_B(1000, 4000, 3000, geometric=True)
+    if name == "c3_real_full":       # the fields of c3_full, solved without complexify
+        return gen_B(5000, 20_000, 15_000, geometric=True)
     if name == "c3_full":            # BASELINE configs[2] at FULL size: T = 5000 x (20 000, 15 000), geometric amplitudes
         return gen_B(5000, 20_000, 15_000, geometric=True)
     if name == "c5_scaled":          # BASELINE configs[4] at T = 1200 x (144 x 288 = 41 472), float32, 3-D

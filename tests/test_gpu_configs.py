@@ -60,6 +60,21 @@ def test_c3_at_full_size_matches_reference():
         assert info[0]["sweeps"] == 0 and info[2]["sweeps"] > 0      # no eigen-decomposition of the first field (Cholesky factor)
 
 
+def test_real_model_at_c3_size_matches_reference():
+    """The fields of configs[2] WITHOUT complexify - the general two-field route (Cholesky factor of G_a in time space, weak
+    block, per-mode consistency check, no second solve) at T = 5000 x (20 000, 15 000) against the real reference
+    (oracle/make_config_goldens.py c3_real_full): all 4999 non-null singular values, leading loadings, rotate(20, 2)."""
+    gold = np.load(os.path.join(GOLDEN_DIR, "config_c3_real_full.npz"))
+    m = _check_config(gold, "c3_real_full", False, 20, 2, "device")
+    sel = np.r_[0:20, 20:4999:61, 4989:4999]
+    for key in m._keys:
+        V = np.asarray(m._V[key][:, :4999])
+        G = V[:, sel].T @ V
+        assert np.max(np.abs(G - np.eye(4999)[sel])) < 1e-6, key
+    if os.environ.get("XMCA_CHOLESKY_FACTOR", "1") != "0":
+        assert "deflate" not in m._device().timings()             # every mode passed the consistency check: one solve
+
+
 def _check_config(gold, name, cplx, n_rot, power, preprocess):
     g = {k[len(name) + 2:]: gold[k] for k in gold.files if k.startswith(name + "__")}
     fields = make_input(name)
