@@ -258,3 +258,15 @@ def test_graded_spectrum_fields_match_oracle(two_fields, cplx, N):
             mine, _ = align_modes(V[:, :nk], gv)
             err = np.max(np.abs(mine - gv), axis=0) / np.max(np.abs(gv), axis=0)
             assert np.max(err) < 1e-5, (key, int(np.argmax(err)), float(np.max(err)))
+
+
+def test_randomised_shapes_and_spectra_match_oracle():
+    """scripts/fuzz_solve.py: 150 random models around the route boundaries (N <> T, analytic / general, T with and without
+    an FFT, one / two fields, f32 / f64, noise / signal / graded / low-rank / duplicated columns) - sigma of every non-null
+    mode, well-separated leading vectors and the orthonormality of all non-null vectors against the numpy oracle."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "scripts", "fuzz_solve.py"), "150", "7"], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
