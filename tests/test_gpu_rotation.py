@@ -88,7 +88,10 @@ def _wide_loadings(n, p, cplx, seed):
 
 
 @pytest.mark.parametrize("n,p,cplx,seed", [(900, 17, False, 55), (600, 20, False, 51), (480, 24, True, 52),
-                                           (640, 32, True, 54), (800, 40, False, 53), (20000, 12, True, 56)])
+                                           (640, 32, True, 54), (800, 40, False, 53), (20000, 12, True, 56),
+                                           # every k-step count of the unrolled Newton-Schulz tiles (rotate.h ns_tile: 5 .. 16)
+                                           (500, 28, False, 57), (500, 36, True, 58), (600, 44, True, 59), (600, 48, True, 60),
+                                           (700, 52, False, 61), (700, 56, False, 62), (700, 60, False, 63), (800, 64, False, 64)])
 def test_varimax_many_modes_matches_oracle(hip, n, p, cplx, seed):
     """More than 16 rotated modes take the multi-tile MFMA accumulation and the LDS Newton-Schulz path, many grid
     points take several tiles per workgroup: same R, B and iteration count as the numpy restatement of rotation.py."""
