@@ -177,7 +177,7 @@ int xmca_reset_timings(xmca_handle* h);
 int xmca_fft(xmca_handle* h, const double* in_re, const double* in_im, int batch, int n, int sign, double* out_re, double* out_im);
 
 /* Device memory kept by the handle.  The solver's temporaries come from a per-handle pool (hipFree waits for the whole
- * device): blocks are kept after a call, up to XMCA_POOL_LIMIT_GB (default 32) in total.
+ * device): blocks are kept after a call, up to XMCA_POOL_LIMIT_GB (default 16) in total; an allocation failure empties every pool of the process first.
  * xmca_pool_bytes reports what is held right now (lanes of rule_n included), xmca_trim_pool gives it back to the driver. */
 int xmca_pool_bytes(xmca_handle* h, int64_t* held_bytes);
 int xmca_trim_pool(xmca_handle* h);

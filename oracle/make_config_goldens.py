@@ -4,6 +4,7 @@
 Run:  PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg python oracle/make_config_goldens.py
 
 Cases (inputs are regenerated from seeds by tests/golden_inputs.py - SURVEY.md Appendix C generators):
+  c1_standin  configs[0]: T = 2920 x (25 x 53, 25 x 27) float32 stand-in of the tutorial split, solve() + rotate(10, 1)
   c2_full     configs[1] at FULL size: EOF T = 2920 x N = 10 000 float64, solve() + rotate(10, 1)
   c3_reduced  configs[2] at T = 1000 x (4000, 3000): MCA, complexify=True, rotate(20, 4) (geometric amplitudes)
   c5_scaled   configs[4] at T = 1200 x 41 472 float32 (3-D input): EOF, solve() + rotate(10, 1)
@@ -30,6 +31,7 @@ from make_goldens import OUT, SvdCounter, import_reference, rel  # noqa: E402
 from golden_inputs import make_input  # noqa: E402
 
 CONFIGS = [  # name, complexify, n_rot, power, modes of V stored, row stride of stored vectors
+    ("c1_standin", False, 10, 1, 10, 1),      # configs[0]: air_temperature-shaped stand-in, T = 2920 x (25 x 53, 25 x 27) float32
     ("c2_full", False, 10, 1, 10, 1),
     ("c3_reduced", True, 20, 4, 20, 1),
     ("c5_scaled", False, 10, 1, 10, 2),
@@ -117,6 +119,15 @@ def main():
             for k, v in config_case(MCA, name, cplx, n_rot, power, n_vec, stride).items():
                 out[name + "__" + k] = v
         dst = os.path.join(OUT, "config_cases.npz")
+        np.savez_compressed(dst, **out)
+        print("wrote %s (%.2f MB)" % (dst, os.path.getsize(dst) / 1e6))
+    if "c1_standin" in only:          # add / refresh this one case inside the existing file (the others take minutes)
+        dst = os.path.join(OUT, "config_cases.npz")
+        out = dict(np.load(dst))
+        name, cplx, n_rot, power, n_vec, stride = [c for c in CONFIGS if c[0] == "c1_standin"][0]
+        out = {k: v for k, v in out.items() if not k.startswith(name + "__")}
+        for k, v in config_case(MCA, name, cplx, n_rot, power, n_vec, stride).items():
+            out[name + "__" + k] = v
         np.savez_compressed(dst, **out)
         print("wrote %s (%.2f MB)" % (dst, os.path.getsize(dst) / 1e6))
     for big in ("c3_full", "c3_real_full"):

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of MCA.solve against the numpy oracle: random shapes around the route boundaries (N <> T, analytic
 / general, FFT-able T or not), rank-deficient and duplicated columns, graded amplitudes, f32 / f64, one or two fields.
-Prints one line per failure and a summary; exit code 1 when anything failed.  usage: fuzz_solve.py [n_cases] [seed]"""
+Prints one line per failure and a summary; exit code 1 when anything failed.
+usage: fuzz_solve.py [n_cases] [seed] [T,T,...]   (default sizes: single-tile eigenproblems; e.g. 300,640,1000 for the
+multi-tile route heuristics of csrc/solver.h)"""
 import os, sys, json
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,10 +14,11 @@ from xmca_amd.array import MCA
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+T_CHOICES = [int(t) for t in sys.argv[3].split(",")] if len(sys.argv) > 3 else [8, 12, 30, 31, 48, 60, 62, 97, 100, 120]
 fails = 0
 routes = {}
 for case in range(n_cases):
-    T = int(rng.choice([8, 12, 30, 31, 48, 60, 62, 97, 100, 120]))
+    T = int(rng.choice(T_CHOICES))
     two = rng.random() < 0.7
     cplx = rng.random() < 0.5
     f32 = rng.random() < 0.25

@@ -125,8 +125,36 @@ def gen_C(T=1200, ny=720, nx=1440, k=30, seed=5):
     return X.reshape(T, ny, nx)
 
 
+def gen_C1(T=2920, shapes=((25, 53), (25, 27)), k=12, seed=9):
+    """Stand-in for BASELINE configs[0] (xr.tutorial air_temperature split west / east: T = 2920 six-hourly steps, 25 x 53
+    and 25 x 27 grid points, float32; the dataset itself is not in the image): smooth standing patterns shared by both
+    halves, an annual + a diurnal cycle and red-noise PCs, white noise on top.  Both fields are narrower than T."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(T)
+    pcs = np.zeros((T, k))
+    pcs[:, 0] = np.cos(2 * np.pi * t / 1460.0)
+    pcs[:, 1] = np.sin(2 * np.pi * t / 4.0)
+    for j in range(2, k):
+        e = rng.standard_normal(T)
+        for i in range(1, T):
+            e[i] += 0.9 * e[i - 1]
+        pcs[:, j] = e / e.std()
+    amp = 12.0 * 0.75 ** np.arange(k)
+    out = []
+    for ny, nx in shapes:
+        y = np.linspace(0, 1, ny)[:, None]
+        x = np.linspace(0, 1, nx)[None, :]
+        pat = np.stack([np.cos(np.pi * (j % 4 + 0.5) * x + 0.3 * j) * np.sin(np.pi * (j // 4 + 1) * y + 0.2 * j) for j in range(k)])
+        pat = pat + (0.1 * rng.standard_normal((k, k)) @ pat.reshape(k, -1)).reshape(k, ny, nx)
+        f = np.einsum('tk,kyx->tyx', pcs * amp, pat) + 0.4 * rng.standard_normal((T, ny, nx))
+        out.append((f + 280.0).astype(np.float32))
+    return tuple(out)
+
+
 def make_input(name):
     """Returns a tuple of 1 or 2 arrays (time first)."""
+    if name == "c1_standin":         # BASELINE configs[0]: air_temperature-shaped stand-in, float32
+        return gen_C1()
     if name == "c2_full":            # BASELINE configs[1] at full size
         return (gen_A(),)
     if name == "c3_reduced":         # BASELINE configs[2] at T = 1000 x (4000, 3000), geometric amplitudes

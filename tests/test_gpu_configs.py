@@ -1,6 +1,8 @@
 """The BASELINE.json configurations through `xmca_amd.array.MCA` on the GPU against golden vectors produced by the REAL
 reference at those sizes (oracle/make_config_goldens.py -> tests/golden/config_cases.npz):
 
+  c1_standin  configs[0]: air_temperature-shaped stand-in, T = 2920 x (25 x 53, 25 x 27) float32 (both fields narrower
+              than T: the explicit-kernel route at multi-tile size), solve() + rotate(10, 1)               (71 iterations)
   c2_full     configs[1] at FULL size: EOF T = 2920 x N = 10 000 float64, solve() + rotate(10, 1)       (530 iterations)
   c3_reduced  configs[2] at T = 1000 x (4000, 3000): complexify=True, rotate(20, 4)                       (413 iterations)
   c5_scaled   configs[4] at T = 1200 x 41 472 float32, 3-D input: EOF, solve() + rotate(10, 1)            (20 iterations)
@@ -23,7 +25,7 @@ from xmca_amd.array import MCA
 
 pytestmark = pytest.mark.gpu
 
-CONFIGS = [("c2_full", False, 10, 1), ("c3_reduced", True, 20, 4), ("c5_scaled", False, 10, 1)]
+CONFIGS = [("c1_standin", False, 10, 1), ("c2_full", False, 10, 1), ("c3_reduced", True, 20, 4), ("c5_scaled", False, 10, 1)]
 
 
 def _rel(a, b):
@@ -39,6 +41,63 @@ def gold():
 @pytest.mark.parametrize("name,cplx,n_rot,power", CONFIGS)
 def test_config_matches_reference(gold, name, cplx, n_rot, power, preprocess):
     _check_config(gold, name, cplx, n_rot, power, preprocess)
+
+
+def test_c1_standin_rule_n_shape_and_normalisation():
+    """configs[0] (tutorial/quickstart.py:7-15 shape): `rule_n(3)` of the unrotated and of the rotated model - modes x
+    runs, every column scaled to the model's total (array.py:1767-1771)."""
+    m = MCA(*make_input("c1_standin"))
+    m.solve()
+    out = m.rule_n(3, seed=5)
+    assert out.shape == (675, 3) and np.all(np.isfinite(out)) and np.all(np.diff(out, axis=0) <= 0)
+    assert np.allclose(out.sum(axis=0), m._get_variance().sum(), rtol=1e-5)
+    m.rotate(10, 1)
+    out = m.rule_n(3, n_modes=4, seed=5)
+    assert out.shape[0] == 4 and 1 <= out.shape[1] <= 3 and np.all(out > 0)
+
+
+def test_c5_at_full_size_against_a_float64_gram_oracle():
+    """configs[4] at FULL size - EOF of T = 1200 x N = 720 x 1440 = 1 036 800 float32 (5 GB upload, 64-bit indexing, a
+    contraction over 10^6 columns) - against what numpy gives on the same input in float64: the T x T Gram matrix in column
+    chunks and its eigenvalues (the dual of xmca/array.py:479; the reference's own sgesdd of a 1200 x 10^6 matrix takes
+    minutes and is accurate to float32 only).  All 1199 non-null singular values, the trace identity, Rayleigh quotients
+    and orthonormality of the 10 leading modes over ALL grid points."""
+    from golden_inputs import gen_C
+    X = gen_C()
+    T = X.shape[0]
+    X2 = X.reshape(T, -1)
+    N = X2.shape[1]
+    m = MCA(X, preprocess="device")
+    m.solve()
+    s = m._singular_values.astype(np.float64)
+    assert m._analysis["rank"] == T and s.shape == (T,)
+    nv = 10
+    V = np.asarray(m._V.head("left", nv), dtype=np.float64)              # N x 10
+    assert V.shape == (N, nv)
+    mean = X2.mean(axis=0, dtype=np.float64)
+    G = np.zeros((T, T))
+    Y = np.zeros((T, nv))
+    step = 1 << 16
+    for c0 in range(0, N, step):
+        C = X2[:, c0:c0 + step].astype(np.float64) - mean[c0:c0 + step]
+        G += C @ C.T
+        Y += C @ V[c0:c0 + step]
+    ref = np.linalg.eigvalsh(G)[::-1] / (T - 1)
+    # trace identity (array.py:597-599: total_covariance = sum of the singular values)
+    assert abs(s.sum() - np.trace(G) / (T - 1)) < 1e-5 * ref.sum()
+    assert abs(float(m._analysis["total_covariance"]) - ref.sum()) < 1e-5 * ref.sum()
+    # all non-null modes: float32 input, float64-class accumulation on the device (30 signal modes 3e5..1.3e6, bulk ~2e2)
+    assert np.max(np.abs(s[:30] - ref[:30]) / ref[:30]) < 2e-5
+    assert np.max(np.abs(s[:T - 1] - ref[:T - 1]) / ref[:T - 1]) < 1e-3
+    assert abs(s[T - 1]) < 1e-5 * ref[0]                                 # the centering null mode
+    # leading vectors over all 1 036 800 grid points
+    assert np.max(np.abs(V.T @ V - np.eye(nv))) < 1e-4
+    ray = np.sum(Y * Y, axis=0) / (T - 1)
+    assert np.max(np.abs(ray - ref[:nv]) / ref[:nv]) < 1e-4
+    YtY = Y.T @ Y / (T - 1)
+    assert np.max(np.abs(YtY - np.diag(np.diag(YtY)))) < 1e-4 * ref[0]
+    m.rotate(10, 1)
+    assert m._rotation_matrix.shape == (10, 10) and np.max(np.abs(m._rotation_matrix.T @ m._rotation_matrix - np.eye(10))) < 1e-6
 
 
 def test_c3_at_full_size_matches_reference():

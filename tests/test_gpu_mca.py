@@ -333,6 +333,55 @@ def test_correlation_maps_match_pearsonr(name, cplx):
             assert np.max(np.abs(p[valid] - p_ref)) < 50 * tol
 
 
+PATTERN_CASES = [  # tag of tests/golden/pattern_cases.npz, input, complexify, rotate(...) or None, where the gauge comes from
+    ("wide_both_std", "wide_both", False, None, "solve:wide_both_std"),
+    ("wide_both_cplx", "wide_both", True, None, "solve:wide_both_cplx"),
+    ("wide_both_std_rot6p1", "wide_both", False, (6, 1, 1e-8), "rot:wide_both_std_n6_p1_t1e-08"),
+    ("wide_both_cplx_rot6p4", "wide_both", True, (6, 4, 1e-8), "rot:wide_both_cplx_n6_p4_t1e-08"),
+    ("unit_both_std_rot10p4", "unit_both", False, (10, 4, 1e-8), "rot:unit_both_std_n10_p4_t1e-08"),
+    ("wide_left_std", "wide_left", False, None, "solve:wide_left_std"),
+    ("sst_prcp_std_rot10p1", "sst_prcp", False, (10, 1, 1e-5), "rot:sst_prcp_std_n10_p1_t1e-05"),
+    ("sst_prcp_cplx", "sst_prcp", True, None, "solve:sst_prcp_cplx"),
+]
+
+
+@pytest.mark.parametrize("tag,name,cplx,rot,gauge", PATTERN_CASES)
+def test_correlation_maps_match_the_reference(rot_gold, tag, name, cplx, rot, gauge):
+    """`homogeneous_patterns(6)` / `heterogeneous_patterns(6)` against the REFERENCE's own output
+    (oracle/make_pattern_goldens.py -> tests/golden/pattern_cases.npz; xmca/array.py:1188-1261, tools/array.py:76-88):
+    real, complexified, Varimax / Promax rotated, one field, NaN columns.  The maps correlate with the REAL part of the
+    PCs, which depends on the sign / phase the SVD happened to give each mode - so the model's unrotated vectors are
+    first put into the reference's gauge (one unit factor per mode, the same on both sides; vectors from the solve /
+    rotate goldens), then everything is compared as is."""
+    gold = np.load(os.path.join(GOLDEN_DIR, "pattern_cases.npz"))
+    kind, gtag = gauge.split(":")
+    gv = rot_gold if kind == "rot" else np.load(os.path.join(GOLDEN_DIR, "solve_cases.npz"))
+    f32 = make_input(name)[0].dtype == np.float32
+    m = MCA(*make_input(name))
+    m.solve(complexify=cplx)
+    Vref = gv[gtag + "__V_left"]
+    nal = Vref.shape[1]
+    V = {k: np.array(m._V[k]) for k in m._keys}
+    _, ph = align_modes(V['left'][:, :nal], Vref)
+    for k in m._keys:
+        V[k][:, :nal] = V[k][:, :nal] / ph
+    m._V = V
+    if rot:
+        m.rotate(*rot)
+    maps = [("hom", m.homogeneous_patterns(6))]
+    if len(m._keys) == 2:
+        maps.append(("het", m.heterogeneous_patterns(6)))
+    tol = 1e-3 if f32 else 1e-8
+    for kind, (rv, pv) in maps:
+        for k in m._keys:
+            r_ref, p_ref = gold["%s__%s_r_%s" % (tag, kind, k)], gold["%s__%s_p_%s" % (tag, kind, k)]
+            assert rv[k].shape == r_ref.shape and pv[k].shape == p_ref.shape
+            nan = np.isnan(r_ref)
+            assert np.array_equal(np.isnan(rv[k]), nan) and np.array_equal(np.isnan(pv[k]), np.isnan(p_ref))
+            assert np.max(np.abs(rv[k][~nan] - r_ref[~nan])) < tol, (tag, kind, k)
+            assert np.allclose(pv[k][~nan], p_ref[~nan], rtol=1e4 * tol, atol=1e-12), (tag, kind, k)
+
+
 # ----------------------------------------------------------------------------------------------
 # bootstrapping replicates on the device (SURVEY.md 8f row 2, array.py:1813-1952)
 # ----------------------------------------------------------------------------------------------

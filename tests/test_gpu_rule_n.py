@@ -70,31 +70,50 @@ def test_rule_n_runs_equal_the_oracle_on_the_same_normals(hip, T, widths, cplx, 
     assert np.array_equal(again, spectra[3:5])
 
 
-def test_rule_n_drops_the_runs_the_reference_drops(hip):
-    """complex white noise, n_rot = 20, power = 4: Varimax needs more than 1000 iterations for most surrogates (SURVEY.md
-    6: 4/4 seeds at T = 1000) - the reference catches the RuntimeError and drops the run (array.py:1762-1763)."""
-    T, widths, seed, n_runs, rot = 150, (400, 300), 99, 8, (30, 4)
-    spectra, kept = hip.rule_n(T, widths[0], widths[1], 2, True, True, rot[0], rot[1], 1e-8, 0, n_runs, seed, np.float64, rot[0])
+_DROP_CASE = dict(T=150, widths=(400, 300), seed=99, n_runs=8, rot=(30, 4))
+
+
+def _drop_case_reference_kept(hip, spectra=None):
+    c = _DROP_CASE
     ref_kept = []
-    for r in range(n_runs):
+    for r in range(c["n_runs"]):
         try:
-            ref = _oracle_run(hip, T, widths, seed, r, True, rot)
+            ref = _oracle_run(hip, c["T"], c["widths"], c["seed"], r, True, c["rot"])
             ref_kept.append(1)
-            assert np.max(np.abs(spectra[r] - ref) / ref) < 1e-4          # (hundreds of iterations on noise: 1e-5 per iteration adds up)
+            if spectra is not None:
+                assert np.max(np.abs(spectra[r] - ref) / ref) < 1e-4      # (hundreds of iterations on noise: 1e-5 per iteration adds up)
         except RuntimeError:
             ref_kept.append(0)
+    return ref_kept
+
+
+def test_rule_n_drops_the_runs_the_reference_drops(hip):
+    """complex white noise, n_rot = 30, power = 4: Varimax needs more than 1000 iterations for most surrogates (SURVEY.md
+    6: 4/4 seeds at T = 1000) - the reference catches the RuntimeError and drops the run (array.py:1762-1763).
+    Kernel level: `xmca_rule_n` reports exactly the runs the oracle keeps on the same normals."""
+    c = _DROP_CASE
+    spectra, kept = hip.rule_n(c["T"], c["widths"][0], c["widths"][1], 2, True, True, c["rot"][0], c["rot"][1], 1e-8, 0, c["n_runs"],
+                               c["seed"], np.float64, c["rot"][0])
+    ref_kept = _drop_case_reference_kept(hip, spectra)
     assert list(kept) == ref_kept
     assert 0 in ref_kept                                                  # the case is only useful if something is dropped
-    # ... and through the class: the dropped runs shrink the run axis
-    rng = np.random.default_rng(0)
-    m = MCA(rng.standard_normal((T, widths[0])), rng.standard_normal((T, widths[1])))
+
+
+def test_rule_n_dropped_runs_shrink_the_run_axis_of_the_class(hip):
+    """... and through the class (array.py:1762-1769): the model's own rotation converges (Hann patterns + cosine PCs,
+    generator B at this size: 134 iterations in the reference), its white-noise surrogates mostly do not, and the
+    dropped runs shrink the run axis of `MCA.rule_n`."""
+    from golden_inputs import gen_B
+    c = _DROP_CASE
+    ref_kept = _drop_case_reference_kept(hip)
+    assert 0 in ref_kept
+    A, B = gen_B(c["T"], c["widths"][0], c["widths"][1], k=30, seed=3)
+    m = MCA(A, B)
     m.solve(complexify=True)
-    try:
-        m.rotate(*rot)
-    except RuntimeError:
-        pytest.skip("the model itself does not converge")
-    out = m.rule_n(n_runs, seed=seed)
-    assert out.shape == (rot[0], int(np.sum(ref_kept)))
+    m.rotate(*c["rot"])                                                   # converges (no RuntimeError)
+    out = m.rule_n(c["n_runs"], seed=c["seed"])
+    assert out.shape == (c["rot"][0], int(np.sum(ref_kept)))
+    assert np.all(np.isfinite(out))
 
 
 @pytest.mark.parametrize("cplx,rot", [(False, None), (True, None), (False, (4, 1))])
@@ -174,6 +193,55 @@ def test_two_ranks_on_one_device_equal_a_single_rank():
     for _, out, out_rot in results:
         assert np.array_equal(out, single)                   # bit for bit: the generator is keyed by (seed, run, side)
         assert np.array_equal(out_rot, single_rot)
+
+
+def _nccl_worker(port, n_runs, q):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import torch
+    import torch.distributed as td
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    td.init_process_group("nccl", rank=0, world_size=1)
+    from golden_inputs import make_input as mk
+    from xmca_amd import _hip, dist
+    from xmca_amd.array import MCA as M
+    m = M(*mk("wide_both"), handle=_hip.Handle(0))
+    m.solve(complexify=True)
+    assert td.get_backend() == "nccl" and dist._comm_device(td, m._device()).type == "cuda"
+    assert dist.broadcast_seed(123456789, m._device()) == 123456789          # RCCL broadcast of the seed
+    out = m.rule_n(n_runs, seed=1000)                                        # spectra through RCCL all_gather
+    m.rotate(5, 2)
+    out_rot = m.rule_n(n_runs, seed=77)
+    q.put((out, out_rot))
+    td.destroy_process_group()
+
+
+def test_rule_n_through_an_rccl_group_of_one_rank():
+    """The `nccl` (= RCCL) branch of xmca_amd/dist.py - seed broadcast and spectra all_gather on CUDA tensors - in a
+    one-rank process group on the one GPU of the test box (array.py:1753-1769 sharded): bit for bit the spectra of a
+    process without torch.distributed."""
+    import torch.multiprocessing as mp
+    from xmca_amd import _hip
+    n_runs = 5
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(port, n_runs, q))
+    p.start()
+    out, out_rot = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    m = MCA(*make_input("wide_both"), handle=_hip.Handle(0))
+    m.solve(complexify=True)
+    assert np.array_equal(out, m.rule_n(n_runs, seed=1000))
+    m.rotate(5, 2)
+    assert np.array_equal(out_rot, m.rule_n(n_runs, seed=77))
 
 
 def test_bench_py_launches_its_own_ranks():

@@ -270,3 +270,14 @@ def test_randomised_shapes_and_spectra_match_oracle():
     r = subprocess.run([sys.executable, os.path.join(repo, "scripts", "fuzz_solve.py"), "150", "7"], capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_randomised_models_at_multi_tile_size_match_oracle():
+    """the same sweep at T = 300 / 640 / 1000 - eigenproblems of several pair tiles, where the route decisions of
+    csrc/solver.h (which factor, weak block, per-mode consistency, deflation; DESIGN.md 2, decision table) apply."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "scripts", "fuzz_solve.py"), "14", "11", "300,640,1000"], capture_output=True,
+                       text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -111,7 +111,8 @@ def test_rule_n_goldens(tag, name, cplx, rot):
     assert mine.shape == g[tag].shape and _rel(mine, g[tag]) < 1e-10
 
 
-@pytest.mark.parametrize("name,cplx,n_rot,power", [("c2_full", False, 10, 1), ("c3_reduced", True, 20, 4), ("c5_scaled", False, 10, 1)])
+@pytest.mark.parametrize("name,cplx,n_rot,power", [("c1_standin", False, 10, 1), ("c2_full", False, 10, 1), ("c3_reduced", True, 20, 4),
+                                                   ("c5_scaled", False, 10, 1)])
 def test_config_goldens(name, cplx, n_rot, power):
     """the BASELINE.json configurations (C2 at full size, C3 / C5 scaled) from the real reference
     (oracle/make_config_goldens.py): sigma, leading loadings, R, variance and the Varimax iteration count."""

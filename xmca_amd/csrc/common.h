@@ -43,15 +43,34 @@ struct Error : std::runtime_error {
 // Re-use is safe without events because a pool serves exactly one stream: whatever still reads a returned block was
 // enqueued on that stream before whatever writes it next.  The calling thread names its pool with a PoolScope (API entry
 // points, lane threads); a DevBuf remembers the pool it came from and returns there from any thread.
-// Blocks above `keep_limit` in total (XMCA_POOL_LIMIT_GB, default 32) are freed straight away; XMCA_POOL=0 switches
-// pooling off; xmca_trim_pool returns what is held.
+// Blocks above `keep_limit` in total (XMCA_POOL_LIMIT_GB, default 16) are freed straight away; XMCA_POOL=0 switches
+// pooling off; xmca_trim_pool returns what is held.  Every pool of the process is registered: when hipMalloc fails, the
+// blocks parked in ALL pools (sibling lanes, the parent handle, other handles) are given back before giving up - hipFree
+// synchronises the device, so a block another stream released earlier is safe to free here.  The lane pools of
+// rule_n / bootstrap are emptied when their call ends if they hold more than 4 GB (run_lanes, xmca_hip.cpp).
 struct DevPool {
+  struct Registry {
+    std::mutex mu;
+    std::vector<DevPool*> pools;
+  };
+  static Registry& registry() {
+    static Registry* r = new Registry;     // never destroyed: pools of static handles may outlive any static of this file
+    return *r;
+  }
+  DevPool() {
+    std::lock_guard<std::mutex> g(registry().mu);
+    registry().pools.push_back(this);
+  }
+  static void trim_all() {
+    std::lock_guard<std::mutex> g(registry().mu);
+    for (DevPool* p : registry().pools) p->trim();
+  }
   std::mutex mu;
   std::multimap<size_t, void*> blocks;     // capacity in bytes -> free block
   size_t held = 0;
   size_t keep_limit = [] {
     const char* e = std::getenv("XMCA_POOL_LIMIT_GB");
-    const double gb = e ? std::atof(e) : 32.0;
+    const double gb = e ? std::atof(e) : 16.0;
     return (size_t)((gb > 0.0 ? gb : 0.0) * (double)((size_t)1 << 30));
   }();
   static bool enabled() {
@@ -73,9 +92,9 @@ struct DevPool {
     void* p = nullptr;
     const size_t want = (bytes + 255) & ~(size_t)255;
     hipError_t e = hipMalloc(&p, want);
-    if (e != hipSuccess) {               // out of memory: give the kept blocks back and try once more
+    if (e != hipSuccess) {               // out of memory: give the kept blocks of every pool back and try once more
       (void)hipGetLastError();
-      trim();
+      trim_all();
       e = hipMalloc(&p, want);
     }
     if (e != hipSuccess)
@@ -100,7 +119,17 @@ struct DevPool {
     blocks.clear();
     held = 0;
   }
-  ~DevPool() { trim(); }
+  ~DevPool() {
+    {
+      std::lock_guard<std::mutex> g(registry().mu);
+      auto& v = registry().pools;
+      for (size_t i = 0; i < v.size(); ++i)
+        if (v[i] == this) { v.erase(v.begin() + (std::ptrdiff_t)i); break; }
+    }
+    trim();
+  }
+  DevPool(const DevPool&) = delete;
+  DevPool& operator=(const DevPool&) = delete;
 };
 
 inline DevPool*& current_pool() {

@@ -133,11 +133,10 @@ inline void fft_batch(hipStream_t st, const FftPlan& plan, int batch, const doub
                       const double* sb, double scale, int n_in = -1, bool conj_in = false, const double* sin_ = nullptr) {
   if (n_in < 0) n_in = plan.n;
   const size_t smem = (size_t)plan.n * 32;
-  static size_t attr_set = 0;
-  if (smem > attr_set) {
-    XMCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fft_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr_set = smem;
-  }
+  // the attribute is per device and several lane threads launch side by side: always ask for the same (maximal) limit
+  // before the launch instead of caching what some other device / thread last set
+  XMCA_CHECK(smem <= (size_t)160 * 1024, XMCA_ERR_UNSUPPORTED, "fft_batch: transform does not fit the LDS of a workgroup");
+  XMCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fft_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipLaunchKernelGGL(fft_batch_kernel, dim3(batch), dim3(256), smem, st, in_r, in_i, in_bs, in_es, n_in, conj_in ? 1 : 0, sin_, plan, sign,
                      out_r, out_i, out_bs, out_es, n_keep, sa, sb, scale);
   XMCA_HIP(hipGetLastError());

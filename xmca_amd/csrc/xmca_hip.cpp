@@ -561,6 +561,12 @@ void run_lanes(xmca_handle* h, int lanes, F&& lane_body) {
     lane->ews.w64.round_ms = lane->ews.w32.round_ms = 0.0;
     lane->ews.w64.round_launches = lane->ews.w32.round_launches = 0;
   }
+  // memory parked in the lane pools is of no use to anybody until the next rule_n / bootstrap call: give large amounts back
+  // (every lane stream has been synchronised above)
+  size_t parked = 0;
+  for (xmca_handle* lane : h->lanes) { std::lock_guard<std::mutex> g(lane->pool.mu); parked += lane->pool.held; }
+  if (parked > ((size_t)4 << 30))
+    for (xmca_handle* lane : h->lanes) lane->pool.trim();
   for (auto& e : errs)
     if (e) std::rethrow_exception(e);
 }

@@ -57,8 +57,9 @@ def sharded_rule_n(dev, n_runs, *, T, Nx, Ny, n_fields, complexify, rotated, p, 
     seed = broadcast_seed(seed, dev)
     begin, end = shard_range(n_runs, rank, world)
     spectra, kept = dev.rule_n(T, Nx, Ny, n_fields, complexify, rotated, p, power, tol, begin, end, seed, dtype, n_out)
-    if td is None or world == 1:
+    if td is None:
         return spectra, kept
+    # (a one-rank group still runs the collective: the same code path whatever the world size)
     import torch
     cdev = _comm_device(td, dev)
     cap = -(-n_runs // world)                      # largest shard
