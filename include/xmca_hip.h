@@ -188,7 +188,9 @@ int xmca_trim_pool(xmca_handle* h);
 int xmca_gemm(xmca_handle* h, const void* A, int64_t lda, int a_kfast, const void* B, int64_t ldb, int b_nfast, double* C,
               int M, int N, int K, int dtype, double alpha, int upper_only, int mirror, int splits);
 /* Hermitian eigendecomposition of an n x n host matrix (interleaved complex when is_complex):
- * lam (n, descending) and Zh (n x n, row i = conj(u_i)); info (4 ints): sweeps, tile, slots, Cholesky LR step taken. */
+ * lam (n, descending) and Zh (n x n, row i = conj(u_i); NULL: eigenvalues only); info (4 ints): sweeps, tile, slots,
+ * bit 0: Cholesky LR step taken, bit 1: solved by tridiagonalisation (csrc/tridiag.h; then no sweeps).  The device time of the
+ * solve is recorded under "eigh_vectors" / "eigh_values" (xmca_get_timings). */
 int xmca_eigh(xmca_handle* h, const double* A, int n, int is_complex, double* lam, double* Zh, int* info);
 /* Blocked Cholesky of an n x n Hermitian host matrix (interleaved complex when is_complex): R (n x n, upper
  * triangular, row-major, same element layout) with R^H R = A + rel_shift * max(diag A) * I; *ok = 0 when a pivot was

@@ -434,18 +434,19 @@ class Handle:
                                         _ptr(C), M, N, K, code, float(alpha), int(upper_only), int(mirror), int(splits)))
         return C
 
-    def eigh(self, A):
-        """Returns (lam descending, U) with A = U diag(lam) U^H."""
+    def eigh(self, A, vectors=True):
+        """Returns (lam descending, U) with A = U diag(lam) U^H; `vectors=False`: (lam, None), eigenvalues only."""
         A = np.asarray(A)
         cplx = np.iscomplexobj(A)
         Ad = np.ascontiguousarray(A, dtype=np.complex128 if cplx else np.float64)
         n = Ad.shape[0]
         lam = np.empty(n)
-        Zh = np.empty((n, n), dtype=Ad.dtype)
+        Zh = np.empty((n, n), dtype=Ad.dtype) if vectors else None
         info = np.zeros(4, dtype=np.int32)
-        self._check(self._lib.xmca_eigh(self._h, _ptr(Ad), n, int(cplx), _ptr(lam), _ptr(Zh), _ptr(info)))
-        self.last_eigh_info = {"sweeps": int(info[0]), "tile": int(info[1]), "slots": int(info[2]), "lr_step": int(info[3])}
-        return lam, Zh.conj().T
+        self._check(self._lib.xmca_eigh(self._h, _ptr(Ad), n, int(cplx), _ptr(lam), _ptr(Zh) if vectors else None, _ptr(info)))
+        self.last_eigh_info = {"sweeps": int(info[0]), "tile": int(info[1]), "slots": int(info[2]), "lr_step": int(info[3]) & 1,
+                               "tridiag": (int(info[3]) >> 1) & 1}
+        return lam, (Zh.conj().T if vectors else None)
 
     def cholesky(self, A, rel_shift=0.0):
         """Returns (R upper triangular with R^H R = A + rel_shift max(diag A) I, ok)."""

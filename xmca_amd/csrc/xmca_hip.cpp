@@ -1127,9 +1127,13 @@ int xmca_eigh(xmca_handle* h, const double* A, int n, int is_complex, double* la
   }
   std::vector<double> lh;
   EvdInfo ei;
-  hermitian_evd(h->st, h->ews, Ap.r(), Ap.i(cplx), n, n, lh, nullptr, Zp.r(), Zp.i(cplx), n, &ei);
+  XMCA_HIP(hipStreamSynchronize(h->st));
+  h->tm.begin(Zh ? "eigh_vectors" : "eigh_values");
+  // Zh == NULL: eigenvalues only (the n_vec = 0 solves of rule_n; tridiagonal route of csrc/tridiag.h)
+  hermitian_evd(h->st, h->ews, Ap.r(), Ap.i(cplx), n, n, lh, nullptr, Zh ? Zp.r() : nullptr, Zh ? Zp.i(cplx) : nullptr, n, &ei);
+  h->tm.end();
   std::memcpy(lam, lh.data(), sizeof(double) * n);
-  if (info) { info[0] = ei.sweeps; info[1] = ei.tile; info[2] = ei.slots; info[3] = ei.lr_step; }
+  if (info) { info[0] = ei.sweeps; info[1] = ei.tile; info[2] = ei.slots; info[3] = ei.lr_step + 2 * ei.tridiag; }
   if (Zh) {
     const size_t no = nn * (cplx ? 2 : 1);
     hipLaunchKernelGGL((pack_rows_kernel<double>), ew_grid((int64_t)nn), dim3(EW_BLOCK), 0, h->st, Zp.r(), Zp.i(cplx), (int64_t)n, n, n,
