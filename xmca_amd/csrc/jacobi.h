@@ -27,6 +27,7 @@
 #include "gemm.h"
 #include "cholesky.h"
 #include "tridiag.h"
+#include "tridiag_vec.h"
 
 namespace xmca {
 
@@ -118,6 +119,7 @@ struct EvdWorkspace {
   jac32::EvdWorkspaceT w32;
   GemmWorkspace gws;             // products of the precision switch
   TrdWorkspace trd;              // tridiagonal route (tridiag.h)
+  TrdVecWorkspace trdv;          // ... its eigenvectors (tridiag_vec.h)
   DevBuf<double> lam_tmp;
   DevBuf<double> mp[6];          // start basis, its Gram matrix, work planes
 };
@@ -171,6 +173,24 @@ inline void hermitian_evd(hipStream_t st, EvdWorkspace& ws, const double* Ar, co
       info->tridiag = 1;
     }
     return;
+  }
+  // with eigenvectors: the same reduction, twisted-factorisation vectors of the tridiagonal matrix, back-transformation by
+  // blocked reflectors and a Newton-Schulz clean-up (tridiag_vec.h).  Spectra with clusters the clean-up cannot repair
+  // (repeated eigenvalues, null spaces of dimension > 1) come back here and take the Jacobi sweeps below.
+  static const int trd_vec_min_n = [] { const char* e = std::getenv("XMCA_TRIDIAG_VEC_MIN_N"); return e ? std::atoi(e) : 768; }();
+  if (Zr && trd_enabled() && n >= trd_vec_min_n && trd_fits(n, Ai != nullptr)) {
+    TrdParams P = trd_reduce(st, ws.trd, Ar, Ai, n, lda, true);
+    std::vector<double> lam_t;
+    trd_eigenvalues(st, ws.trd, P, lam_t, lam_dev, ws.lam_tmp, ws.trdv.lam_asc.ensure((size_t)n));
+    if (trd_eigenvectors(st, ws.trd, ws.trdv, ws.gws, P, Ai != nullptr, Zr, Zi, ldz)) {
+      XMCA_HIP(hipStreamSynchronize(st));
+      lam_host = lam_t;
+      if (info) {
+        *info = EvdInfo{};
+        info->tridiag = 1;
+      }
+      return;
+    }
   }
   // stop after the first sweep that leaves no off-diagonal entry above 1e-10 * max|diag| behind: with the (at least
   // fast-linear, normally quadratic) convergence the next sweep would only confirm it

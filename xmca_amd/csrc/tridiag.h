@@ -47,6 +47,7 @@ struct TrdParams {
   double* e;           // sub-diagonal (real)
   double* Vr;          // reflectors, row j = v_j (n x ld), or nullptr
   double* Vi;
+  unsigned long long* prof;   // (XMCA_TRD_PROF) 8 s_memtime stamps of workgroup 0 per launch, or nullptr
 };
 
 __device__ __forceinline__ double trd_wave_sum(double x) {
@@ -66,7 +67,22 @@ __device__ __forceinline__ double trd_block_sum(double x, double* red) {
   return s;
 }
 
-template <bool CPLX>
+// NS: LDS slots per thread (the vectors have at most NS * TRD_THREADS slots); PF: 128-column chunks of a wave's first row
+// requested before the prologue starts.
+constexpr int TRD_PF = 4;
+template <int NWAVES>
+__device__ __forceinline__ double trd_block_sum_n(double x, double* red) {
+  x = trd_wave_sum(x);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+  __syncthreads();
+  double s = 0.0;
+#pragma unroll
+  for (int w = 0; w < NWAVES; ++w) s += red[w];
+  return s;
+}
+
+template <bool CPLX, int NS>
 __global__ __launch_bounds__(TRD_THREADS) void trd_step_kernel(TrdParams P, int j, int wgs_prev) {
   extern __shared__ __attribute__((aligned(16))) double trd_lds[];
   __shared__ double red[TRD_THREADS / 64];
@@ -84,40 +100,86 @@ __global__ __launch_bounds__(TRD_THREADS) void trd_step_kernel(TrdParams P, int 
   double* sxi = swi + (CPLX ? L : 0);
   const int prev = (j + 1) & 1, cur = j & 1;
   const int m = n - j - 1;                         // length of the reflector
+  const bool prof = P.prof && blockIdx.x == 0 && tid == 0;
+  if (prof) P.prof[8 * j + 0] = __builtin_amdgcn_s_memtime();
 
+  // ---- every global load of the prologue is requested up front (one memory latency instead of four) ----
+  double gr = 0.0, gi = 0.0, tpr = 0.0, tpi = 0.0;
+  if (j > 0) {
+    if (tid < wgs_prev) {
+      gr = P.gp[prev][0][tid];
+      if (CPLX) gi = P.gp[prev][1][tid];
+    }
+    tpr = P.tau[0][j - 1];
+    if (CPLX) tpi = P.tau[1][j - 1];
+  }
+  double vre[NS], pre[NS], are[NS], vim[NS], pim[NS], aim[NS];
+#pragma unroll
+  for (int t = 0; t < NS; ++t) {
+    const int s = tid + t * TRD_THREADS, k = b0 + s;
+    const bool in = s < L && k >= j && k < n;
+    vre[t] = pre[t] = are[t] = vim[t] = pim[t] = aim[t] = 0.0;
+    if (in) {
+      are[t] = P.Ar[(int64_t)j * P.ld + k];
+      if (CPLX) aim[t] = P.Ai[(int64_t)j * P.ld + k];
+      if (j > 0) {
+        vre[t] = P.vb[prev][0][k];
+        pre[t] = P.pb[prev][0][k];
+        if (CPLX) {
+          vim[t] = P.vb[prev][1][k];
+          pim[t] = P.pb[prev][1][k];
+        }
+      }
+    }
+  }
+  // ... and the first chunks of this wave's first row of the pass
+  const int wave = tid >> 6, lane = tid & 63;
+  const int rs = wave & (TRD_ROWS - 1), half = wave >> 2;
+  const int stride = TRD_ROWS * gridDim.x;
+  int i = TRD_ROWS * blockIdx.x + rs;
+  if (i < j + 1) i += ((j + 1 - i + stride - 1) / stride) * stride;
+  const int ks = (j + 1) & ~1;                     // first column of the pass (even; column j itself when j is even: harmless)
+  const int ke = (n + 1) & ~1;                     // one past the last column pair (padding column is zero)
+  const int kmid = ks + ((((ke - ks) >> 1) + 127) & ~127);
+  const int k_lo = half ? kmid : ks, k_hi = half ? ke : (kmid < ke ? kmid : ke);
+  double2 fa[TRD_PF], fb[TRD_PF];
+#pragma unroll
+  for (int c = 0; c < TRD_PF; ++c) {
+    const int k = k_lo + 2 * lane + 128 * c;
+    fa[c] = make_double2(0.0, 0.0);
+    fb[c] = make_double2(0.0, 0.0);
+    if (i < n && k < k_hi) {
+      fa[c] = *reinterpret_cast<const double2*>(P.Ar + (int64_t)i * P.ld + k);
+      if (CPLX) fb[c] = *reinterpret_cast<const double2*>(P.Ai + (int64_t)i * P.ld + k);
+    }
+  }
+
+  if (prof) P.prof[8 * j + 1] = __builtin_amdgcn_s_memtime();
   // ---- alpha of the previous step: alpha = -1/2 tau (p^H v) ----
   double ar_ = 0.0, ai_ = 0.0;
   if (j > 0) {
-    double gr = 0.0, gi = 0.0;
-    for (int g = tid; g < wgs_prev; g += TRD_THREADS) {
-      gr += P.gp[prev][0][g];
-      if (CPLX) gi += P.gp[prev][1][g];
-    }
     gr = trd_block_sum(gr, red);
     if (CPLX) gi = trd_block_sum(gi, red);
-    const double tr = P.tau[0][j - 1], ti = CPLX ? P.tau[1][j - 1] : 0.0;
-    ar_ = -0.5 * (tr * gr - ti * gi);
-    ai_ = -0.5 * (tr * gi + ti * gr);
+    ar_ = -0.5 * (tpr * gr - tpi * gi);
+    ai_ = -0.5 * (tpr * gi + tpi * gr);
   }
+  if (prof) P.prof[8 * j + 2] = __builtin_amdgcn_s_memtime();
   // ---- v_{j-1}, w_{j-1} = p_{j-1} + alpha v_{j-1} (global indices j .. n-1), zero elsewhere ----
-  for (int s = tid; s < L; s += TRD_THREADS) {
-    const int k = b0 + s;
-    double vr = 0.0, vi = 0.0, wr = 0.0, wi = 0.0;
-    if (j > 0 && k >= j && k < n) {
-      vr = P.vb[prev][0][k];
-      const double pr = P.pb[prev][0][k];
+#pragma unroll
+  for (int t = 0; t < NS; ++t) {
+    const int s = tid + t * TRD_THREADS;
+    if (s < L) {
+      svr[s] = vre[t];
       if (CPLX) {
-        vi = P.vb[prev][1][k];
-        const double pi = P.pb[prev][1][k];
-        wr = pr + ar_ * vr - ai_ * vi;
-        wi = pi + ar_ * vi + ai_ * vr;
+        svi[s] = vim[t];
+        pre[t] = pre[t] + ar_ * vre[t] - ai_ * vim[t];      // (p <- w)
+        pim[t] = pim[t] + ar_ * vim[t] + ai_ * vre[t];
+        swi[s] = pim[t];
       } else {
-        wr = pr + ar_ * vr;
+        pre[t] = pre[t] + ar_ * vre[t];
       }
+      swr[s] = pre[t];
     }
-    svr[s] = vr;
-    swr[s] = wr;
-    if (CPLX) { svi[s] = vi; swi[s] = wi; }
   }
   __syncthreads();
   // ---- column j of the current matrix: x_k = conj(a_jk) - v_k conj(w_j) - w_k conj(v_j), k >= j ----
@@ -125,30 +187,34 @@ __global__ __launch_bounds__(TRD_THREADS) void trd_step_kernel(TrdParams P, int 
   const double wjr = swr[sj], vjr = svr[sj];
   const double wji = CPLX ? swi[sj] : 0.0, vji = CPLX ? svi[sj] : 0.0;
   double xn2 = 0.0;
-  for (int s = tid; s < L; s += TRD_THREADS) {
-    const int k = b0 + s;
-    double xr = 0.0, xi = 0.0;
-    if (k >= j && k < n) {
-      const double a_r = P.Ar[(int64_t)j * P.ld + k];
-      if (CPLX) {
-        const double a_i = P.Ai[(int64_t)j * P.ld + k];
-        xr = a_r - (svr[s] * wjr + svi[s] * wji) - (swr[s] * vjr + swi[s] * vji);
-        xi = -a_i - (svi[s] * wjr - svr[s] * wji) - (swi[s] * vjr - swr[s] * vji);
-      } else {
-        xr = a_r - svr[s] * wjr - swr[s] * vjr;
+#pragma unroll
+  for (int t = 0; t < NS; ++t) {
+    const int s = tid + t * TRD_THREADS, k = b0 + s;
+    if (s < L) {
+      double xr = 0.0, xi = 0.0;
+      if (k >= j && k < n) {
+        if (CPLX) {
+          xr = are[t] - (vre[t] * wjr + vim[t] * wji) - (pre[t] * vjr + pim[t] * vji);
+          xi = -aim[t] - (vim[t] * wjr - vre[t] * wji) - (pim[t] * vjr - pre[t] * vji);
+        } else {
+          xr = are[t] - vre[t] * wjr - pre[t] * vjr;
+        }
+        if (k == j) {
+          dj_sh = xr;
+          xr = 0.0;
+          xi = 0.0;
+        } else if (k > j + 1) {
+          xn2 += xr * xr + xi * xi;
+        }
       }
-      if (k == j) {
-        dj_sh = xr;
-        xr = 0.0;
-        xi = 0.0;
-      } else if (k > j + 1) {
-        xn2 += xr * xr + xi * xi;
-      }
+      sxr[s] = xr;
+      if (CPLX) sxi[s] = xi;
+      are[t] = xr;                                 // kept for the scaling below
+      aim[t] = xi;
     }
-    sxr[s] = xr;
-    if (CPLX) sxi[s] = xi;
   }
   xn2 = trd_block_sum(xn2, red);                   // (its barriers also publish sx and dj_sh)
+  if (prof) P.prof[8 * j + 3] = __builtin_amdgcn_s_memtime();
   if (m == 0) {                                    // last launch: only the last diagonal entry
     if (blockIdx.x == 0 && tid == 0) P.d[j] = dj_sh;
     return;
@@ -168,51 +234,41 @@ __global__ __launch_bounds__(TRD_THREADS) void trd_step_kernel(TrdParams P, int 
     sci = -di * dn;
   }
   __syncthreads();                                 // everybody has read a0 before it is overwritten
-  for (int s = tid; s < L; s += TRD_THREADS) {
-    const int k = b0 + s;
-    if (k == j + 1) {
-      sxr[s] = 1.0;
-      if (CPLX) sxi[s] = 0.0;
-    } else if (k > j + 1 && k < n) {
-      const double xr = sxr[s];
-      if (CPLX) {
-        const double xi = sxi[s];
-        sxr[s] = xr * scr - xi * sci;
-        sxi[s] = xr * sci + xi * scr;
+#pragma unroll
+  for (int t = 0; t < NS; ++t) {
+    const int s = tid + t * TRD_THREADS, k = b0 + s;
+    if (s < L && k > j && k < n) {
+      double vr, vi = 0.0;
+      if (k == j + 1) {
+        vr = 1.0;
+      } else if (CPLX) {
+        vr = are[t] * scr - aim[t] * sci;
+        vi = are[t] * sci + aim[t] * scr;
       } else {
-        sxr[s] = xr * scr;
+        vr = are[t] * scr;
+      }
+      sxr[s] = vr;
+      if (CPLX) sxi[s] = vi;
+      if (blockIdx.x == 0) {
+        P.vb[cur][0][k] = vr;
+        if (CPLX) P.vb[cur][1][k] = vi;
+        if (P.Vr) {                                  // (tau = 0: H_j = I - the stored reflector is the zero vector)
+          const bool live = tr != 0.0 || ti != 0.0;
+          P.Vr[(int64_t)j * P.ld + k] = live ? vr : 0.0;
+          if (CPLX) P.Vi[(int64_t)j * P.ld + k] = live ? vi : 0.0;
+        }
       }
     }
+  }
+  if (blockIdx.x == 0 && tid == 0) {
+    P.d[j] = dj_sh;
+    P.e[j] = beta;
+    P.tau[0][j] = tr;
+    if (CPLX) P.tau[1][j] = ti;
   }
   __syncthreads();
-  if (blockIdx.x == 0) {
-    for (int k = j + 1 + tid; k < n; k += TRD_THREADS) {
-      const int s = k - b0;
-      P.vb[cur][0][k] = sxr[s];
-      if (CPLX) P.vb[cur][1][k] = sxi[s];
-      if (P.Vr) {
-        P.Vr[(int64_t)j * P.ld + k] = sxr[s];
-        if (CPLX) P.Vi[(int64_t)j * P.ld + k] = sxi[s];
-      }
-    }
-    if (tid == 0) {
-      P.d[j] = dj_sh;
-      P.e[j] = beta;
-      P.tau[0][j] = tr;
-      if (CPLX) P.tau[1][j] = ti;
-    }
-  }
+  if (prof) P.prof[8 * j + 4] = __builtin_amdgcn_s_memtime();
   // ---- pass over the trailing rows: apply the update of step j-1, multiply by v_j ----
-  const int wave = tid >> 6, lane = tid & 63;
-  const int rs = wave & (TRD_ROWS - 1), half = wave >> 2;
-  const int stride = TRD_ROWS * gridDim.x;
-  const int rslot = TRD_ROWS * blockIdx.x + rs;
-  int i = rslot;
-  if (i < j + 1) i += ((j + 1 - i + stride - 1) / stride) * stride;
-  const int ks = (j + 1) & ~1;                     // first column of the pass (even; column j itself when j is even: harmless)
-  const int ke = (n + 1) & ~1;                     // one past the last column pair (padding column is zero)
-  const int kmid = ks + ((((ke - ks) >> 1) + 127) & ~127);
-  const int k_lo = half ? kmid : ks, k_hi = half ? ke : (kmid < ke ? kmid : ke);
   int it = 0;
   for (; i < n; i += stride, ++it) {
     const int si = i - b0;
@@ -221,15 +277,12 @@ __global__ __launch_bounds__(TRD_THREADS) void trd_step_kernel(TrdParams P, int 
     double* rowr = P.Ar + (int64_t)i * P.ld;
     double* rowi = CPLX ? P.Ai + (int64_t)i * P.ld : nullptr;
     double accr = 0.0, acci = 0.0;
-#pragma unroll 2
-    for (int k = k_lo + 2 * lane; k < k_hi; k += 128) {
+    auto body = [&](int k, double2 a, double2 b) {
       const int s = k - b0;
-      double2 a = *reinterpret_cast<const double2*>(rowr + k);
       const double2 wk = *reinterpret_cast<const double2*>(swr + s);
       const double2 vk = *reinterpret_cast<const double2*>(svr + s);
       const double2 xk = *reinterpret_cast<const double2*>(sxr + s);
       if (CPLX) {
-        double2 b = *reinterpret_cast<const double2*>(rowi + k);
         const double2 wki = *reinterpret_cast<const double2*>(swi + s);
         const double2 vki = *reinterpret_cast<const double2*>(svi + s);
         const double2 xki = *reinterpret_cast<const double2*>(sxi + s);
@@ -251,6 +304,21 @@ __global__ __launch_bounds__(TRD_THREADS) void trd_step_kernel(TrdParams P, int 
         accr += a.x * xk.x;
         accr += a.y * xk.y;
       }
+    };
+    int k = k_lo + 2 * lane;
+    if (it == 0) {
+#pragma unroll
+      for (int c = 0; c < TRD_PF; ++c) {
+        if (k < k_hi) body(k, fa[c], fb[c]);
+        k += 128;
+      }
+    }
+#pragma unroll 2
+    for (; k < k_hi; k += 128) {
+      const double2 a = *reinterpret_cast<const double2*>(rowr + k);
+      double2 b = make_double2(0.0, 0.0);
+      if (CPLX) b = *reinterpret_cast<const double2*>(rowi + k);
+      body(k, a, b);
     }
     accr = trd_wave_sum(accr);
     if (CPLX) acci = trd_wave_sum(acci);
@@ -260,8 +328,9 @@ __global__ __launch_bounds__(TRD_THREADS) void trd_step_kernel(TrdParams P, int 
     }
   }
   __syncthreads();
+  if (prof) P.prof[8 * j + 5] = __builtin_amdgcn_s_memtime();
   // ---- p_i = tau (first half + second half), partial sum of conj(p_i) v_i ----
-  double gr = 0.0, gi = 0.0;
+  double gor = 0.0, goi = 0.0;
   if (tid < TRD_ROWS * TRD_MAX_ITERS) {
     const int it2 = tid >> 2, rs2 = tid & (TRD_ROWS - 1);
     int i2 = TRD_ROWS * blockIdx.x + rs2;
@@ -275,15 +344,429 @@ __global__ __launch_bounds__(TRD_THREADS) void trd_step_kernel(TrdParams P, int 
       if (CPLX) P.pb[cur][1][i2] = pi;
       const int s = i2 - b0;
       const double vr = sxr[s], vi = CPLX ? sxi[s] : 0.0;
-      gr = pr * vr + pi * vi;          // conj(p) v
-      gi = pr * vi - pi * vr;
+      gor = pr * vr + pi * vi;          // conj(p) v
+      goi = pr * vi - pi * vr;
     }
   }
-  gr = trd_block_sum(gr, red);
-  if (CPLX) gi = trd_block_sum(gi, red);
+  gor = trd_block_sum(gor, red);
+  if (CPLX) goi = trd_block_sum(goi, red);
   if (tid == 0) {
-    P.gp[cur][0][blockIdx.x] = gr;
-    if (CPLX) P.gp[cur][1][blockIdx.x] = gi;
+    P.gp[cur][0][blockIdx.x] = gor;
+    if (CPLX) P.gp[cur][1][blockIdx.x] = goi;
+  }
+  if (prof) P.prof[8 * j + 6] = __builtin_amdgcn_s_memtime();
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// The same reduction as ONE persistent launch with the trailing matrix RESIDENT IN REGISTERS (trd_resident_kernel).
+// The launch-per-column form above streams the trailing matrix through HBM once per column (read + write: 133 GB for
+// n = 2920, 6 TB/s -> 22 of its 39 ms).  Here every wave keeps RR whole rows of the matrix in its VGPRs (lane l holds the
+// column pairs 128 c + 2 l of a row: NC double2 per row and plane; 256 workgroups x 4 waves (one per SIMD: 512 registers
+// per lane) x RR rows = the last 1024 RR
+// rows - the ones that live longest; earlier rows are streamed from global memory by their owner wave until they die), the
+// three vectors of a step live in LDS as before, and a column costs one all-to-all exchange instead of a pass over HBM:
+//   pass: every wave updates its rows, p_i = tau_j (row . v_j) -> published (write-through stores) together with the
+//         workgroup's partial p^H v and, by its owner, row j+1 of the stored matrix; drain; ONE epoch flag per workgroup;
+//   exchange: one wave polls the flags of all workgroups (bounded), then every thread reads p, the partial sums and row
+//         j+1 with agent-scope (sc1) loads - cdna_hip_programming.md G16 form R1 with sc1 loads in place of the acquire;
+//   prologue: as in the step kernel, redundantly in every workgroup.
+// Buffers alternate with the column parity (a workgroup is at most one column ahead of the slowest).  The grid must be
+// resident: one workgroup per CU (the LDS request guarantees it is alone), launched under a process-wide mutex so that two
+// lanes never interleave two persistent grids; a workgroup that is missing makes every spin run out -> give_up -> the host
+// repeats the reduction with the launch-per-column kernels.
+struct TrdSync {
+  double* pub[2][2];      // [parity][re / im]  p_j by global row index
+  double* gpart[2][2];    // partial p^H v per workgroup
+  double* rowbuf[2][2];   // row j of the stored matrix (parity of j), by global column index
+  unsigned int* flags;    // epoch per workgroup
+  int* give_up;
+};
+
+__device__ __forceinline__ double trd_ld_sc1(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void trd_st_sc1(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+constexpr int TRD_RES_THREADS = 256;   // one wave per SIMD: 512 registers per lane for the resident rows
+template <bool CPLX, int NC, int RR>
+__global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams P, TrdSync S, int first_res) {
+  extern __shared__ __attribute__((aligned(16))) double trd_lds[];
+  __shared__ double red[TRD_RES_THREADS / 64];
+  __shared__ double gam_sh[TRD_RES_THREADS / 64][2];
+  __shared__ double dj_sh;
+  __shared__ int give_up_sh;
+  constexpr int LV = NC * 128;                     // slots per vector = padded matrix order
+  constexpr int NS = LV / TRD_RES_THREADS;             // slots per thread
+  static_assert(LV % TRD_RES_THREADS == 0, "NC must be even");
+  const int n = P.n;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: row ownership tests become scalar branches)
+  const int nwg = (int)gridDim.x, NW = nwg * (TRD_RES_THREADS / 64), g = (int)blockIdx.x * (TRD_RES_THREADS / 64) + wave;
+  double* bV[2] = {trd_lds, trd_lds + 3 * LV};                       // v_{j-1}   (re, im)
+  double* bW[2] = {trd_lds + LV, trd_lds + 4 * LV};                  // w_{j-1}
+  double* bX[2] = {trd_lds + 2 * LV, trd_lds + 5 * LV};              // column j -> v_j
+  // ---- resident rows -> registers ----
+  double2 ar[RR][NC], ai[RR][NC];
+#pragma unroll
+  for (int t = 0; t < RR; ++t) {
+    const int i = first_res + g + NW * t;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      ar[t][c] = make_double2(0.0, 0.0);
+      ai[t][c] = make_double2(0.0, 0.0);
+      if (i < n) {
+        ar[t][c] = *reinterpret_cast<const double2*>(P.Ar + (int64_t)i * P.ld + 128 * c + 2 * lane);
+        if (CPLX) ai[t][c] = *reinterpret_cast<const double2*>(P.Ai + (int64_t)i * P.ld + 128 * c + 2 * lane);
+      }
+    }
+  }
+  for (int s = tid; s < LV; s += TRD_RES_THREADS) {
+    bV[0][s] = 0.0; bW[0][s] = 0.0; bX[0][s] = 0.0;
+    if (CPLX) { bV[1][s] = 0.0; bW[1][s] = 0.0; bX[1][s] = 0.0; }
+  }
+  if (tid == 0) give_up_sh = 0;
+  double tpr = 0.0, tpi = 0.0;                     // tau of the previous column
+  __syncthreads();
+
+  const bool prof = P.prof && blockIdx.x == 0 && tid == 0;
+  for (int j = 0; j < n; ++j) {
+    const int prev = (j + 1) & 1, cur = j & 1;
+    if (prof) P.prof[8 * j + 0] = __builtin_amdgcn_s_memtime();
+    const int m = n - j - 1;
+    // ---- prologue: p_{j-1}, its partial sums, row j ----
+    double gr = 0.0, gi = 0.0;
+    if (j > 0 && tid < nwg) {
+      gr = trd_ld_sc1(S.gpart[prev][0] + tid);
+      if (CPLX) gi = trd_ld_sc1(S.gpart[prev][1] + tid);
+    }
+    // (everything of the prologue goes through LDS: the registers belong to the resident rows)
+    double ar_ = 0.0, ai_ = 0.0;
+    if (j > 0) {
+      gr = trd_block_sum_n<TRD_RES_THREADS / 64>(gr, red);
+      if (CPLX) gi = trd_block_sum_n<TRD_RES_THREADS / 64>(gi, red);
+      ar_ = -0.5 * (tpr * gr - tpi * gi);
+      ai_ = -0.5 * (tpr * gi + tpi * gr);
+    }
+    // (slots below column j are dead - nothing reads them any more - and are skipped by whole strides of the workgroup;
+    //  the loads of four slots are requested together: they are agent-scope loads the compiler does not move by itself)
+    constexpr int NB = 4;
+#pragma unroll
+    for (int tb = 0; tb < NS; tb += NB) {
+      if ((tb + NB) * TRD_RES_THREADS > j) {
+        double rr_[NB], ri_[NB], pr_[NB], pi_[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          const int k = tid + (tb + u) * TRD_RES_THREADS;
+          const bool in = tb + u < NS && k >= j && k < n;
+          rr_[u] = ri_[u] = pr_[u] = pi_[u] = 0.0;
+          if (in) {
+            if (j == 0) {
+              rr_[u] = P.Ar[k];
+              if (CPLX) ri_[u] = P.Ai[k];
+            } else {
+              rr_[u] = trd_ld_sc1(S.rowbuf[cur][0] + k);
+              pr_[u] = trd_ld_sc1(S.pub[prev][0] + k);
+              if (CPLX) {
+                ri_[u] = trd_ld_sc1(S.rowbuf[cur][1] + k);
+                pi_[u] = trd_ld_sc1(S.pub[prev][1] + k);
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          const int k = tid + (tb + u) * TRD_RES_THREADS;
+          if (tb + u < NS) {
+            const bool in = k >= j && k < n;
+            double wr = 0.0, wi = 0.0;
+            if (in && j > 0) {
+              const double vr = bV[0][k];
+              if (CPLX) {
+                const double vi = bV[1][k];
+                wr = pr_[u] + ar_ * vr - ai_ * vi;
+                wi = pi_[u] + ar_ * vi + ai_ * vr;
+              } else {
+                wr = pr_[u] + ar_ * vr;
+              }
+            }
+            bW[0][k] = wr;
+            bX[0][k] = rr_[u];                       // conj(row j) for now
+            if (CPLX) {
+              bW[1][k] = wi;
+              bX[1][k] = -ri_[u];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const double wjr = bW[0][j], vjr = j > 0 ? bV[0][j] : 0.0;
+    const double wji = CPLX ? bW[1][j] : 0.0, vji = (CPLX && j > 0) ? bV[1][j] : 0.0;
+    double xn2 = 0.0;
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+      const int k = tid + t * TRD_RES_THREADS;
+      if ((t + 1) * TRD_RES_THREADS <= j) continue;          // dead stride
+      double xr = 0.0, xi = 0.0;
+      if (k >= j && k < n) {
+        const double vr = j > 0 ? bV[0][k] : 0.0, wr = bW[0][k];
+        if (CPLX) {
+          const double vi = j > 0 ? bV[1][k] : 0.0, wi = bW[1][k];
+          xr = bX[0][k] - (vr * wjr + vi * wji) - (wr * vjr + wi * vji);
+          xi = bX[1][k] - (vi * wjr - vr * wji) - (wi * vjr - wr * vji);
+        } else {
+          xr = bX[0][k] - vr * wjr - wr * vjr;
+        }
+        if (k == j) {
+          dj_sh = xr;
+          xr = 0.0;
+          xi = 0.0;
+        } else if (k > j + 1) {
+          xn2 += xr * xr + xi * xi;
+        }
+      }
+      bX[0][k] = xr;
+      if (CPLX) bX[1][k] = xi;
+    }
+    xn2 = trd_block_sum_n<TRD_RES_THREADS / 64>(xn2, red);
+    if (m == 0) {
+      if (blockIdx.x == 0 && tid == 0) P.d[j] = dj_sh;
+      break;
+    }
+    if (prof) P.prof[8 * j + 2] = __builtin_amdgcn_s_memtime();
+    const double a0r = bX[0][j + 1], a0i = CPLX ? bX[1][j + 1] : 0.0;
+    double beta, tr, ti = 0.0, scr = 0.0, sci = 0.0;
+    if (xn2 == 0.0 && a0i == 0.0) {
+      beta = a0r;
+      tr = 0.0;
+    } else {
+      beta = -copysign(sqrt(a0r * a0r + a0i * a0i + xn2), a0r);
+      tr = (beta - a0r) / beta;
+      ti = -a0i / beta;
+      const double dr = a0r - beta, di = a0i, dn = 1.0 / (dr * dr + di * di);
+      scr = dr * dn;
+      sci = -di * dn;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+      const int k = tid + t * TRD_RES_THREADS;
+      if ((t + 1) * TRD_RES_THREADS <= j) continue;          // dead stride
+      if (k > j && k < n) {
+        double vr, vi = 0.0;
+        if (k == j + 1) {
+          vr = 1.0;
+        } else if (CPLX) {
+          const double xr = bX[0][k], xi = bX[1][k];
+          vr = xr * scr - xi * sci;
+          vi = xr * sci + xi * scr;
+        } else {
+          vr = bX[0][k] * scr;
+        }
+        bX[0][k] = vr;
+        if (CPLX) bX[1][k] = vi;
+        if (blockIdx.x == 0 && P.Vr) {               // (tau = 0: H_j = I - the stored reflector is the zero vector)
+          const bool live = tr != 0.0 || ti != 0.0;
+          P.Vr[(int64_t)j * P.ld + k] = live ? vr : 0.0;
+          if (CPLX) P.Vi[(int64_t)j * P.ld + k] = live ? vi : 0.0;
+        }
+      }
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+      P.d[j] = dj_sh;
+      P.e[j] = beta;
+      P.tau[0][j] = tr;
+      if (CPLX) P.tau[1][j] = ti;
+    }
+    __syncthreads();
+    if (prof) P.prof[8 * j + 3] = __builtin_amdgcn_s_memtime();
+    // ---- pass: resident rows in registers, early rows streamed from global memory ----
+    // No liveness tests per row: a dead row (i <= j) keeps being updated - nobody reads its p_i (consumers start at j+1),
+    // and v_j[i] = 0 keeps it out of p^H v.  Only rows beyond the matrix (i >= n) are skipped, wave-uniformly.
+    const int c0 = (j + 1) >> 7;                    // chunks below hold dead columns only
+    double gwr = 0.0, gwi = 0.0;
+    if (first_res + g < n) {
+      double vpr[RR], vpi[RR], wpr[RR], wpi[RR], accr[RR], acci[RR];
+      bool any = false;
+#pragma unroll
+      for (int t = 0; t < RR; ++t) {
+        const int i = first_res + g + NW * t;
+        const int ii = i < n ? i : 0;
+        any |= i < n && i > j;
+        vpr[t] = bV[0][ii]; wpr[t] = bW[0][ii];
+        vpi[t] = CPLX ? bV[1][ii] : 0.0; wpi[t] = CPLX ? bW[1][ii] : 0.0;
+        accr[t] = 0.0; acci[t] = 0.0;
+      }
+      if (any) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          if (c >= c0) {
+            const int k = 128 * c + 2 * lane;
+            const double2 wk = *reinterpret_cast<const double2*>(bW[0] + k);
+            const double2 vk = *reinterpret_cast<const double2*>(bV[0] + k);
+            const double2 xk = *reinterpret_cast<const double2*>(bX[0] + k);
+            double2 wki = make_double2(0.0, 0.0), vki = wki, xki = wki;
+            if (CPLX) {
+              wki = *reinterpret_cast<const double2*>(bW[1] + k);
+              vki = *reinterpret_cast<const double2*>(bV[1] + k);
+              xki = *reinterpret_cast<const double2*>(bX[1] + k);
+            }
+#pragma unroll
+            for (int t = 0; t < RR; ++t) {
+              if (first_res + g + NW * t < n) {            // wave-uniform
+                double2 a = ar[t][c];
+                if (CPLX) {
+                  double2 b = ai[t][c];
+                  // a -= v'_i conj(w'_k) + w'_i conj(v'_k)
+                  a.x = fma(-vpr[t], wk.x, a.x);  a.x = fma(-vpi[t], wki.x, a.x);  a.x = fma(-wpr[t], vk.x, a.x);  a.x = fma(-wpi[t], vki.x, a.x);
+                  b.x = fma(-vpi[t], wk.x, b.x);  b.x = fma(vpr[t], wki.x, b.x);   b.x = fma(-wpi[t], vk.x, b.x);  b.x = fma(wpr[t], vki.x, b.x);
+                  a.y = fma(-vpr[t], wk.y, a.y);  a.y = fma(-vpi[t], wki.y, a.y);  a.y = fma(-wpr[t], vk.y, a.y);  a.y = fma(-wpi[t], vki.y, a.y);
+                  b.y = fma(-vpi[t], wk.y, b.y);  b.y = fma(vpr[t], wki.y, b.y);   b.y = fma(-wpi[t], vk.y, b.y);  b.y = fma(wpr[t], vki.y, b.y);
+                  ai[t][c] = b;
+                  accr[t] = fma(a.x, xk.x, accr[t]);  accr[t] = fma(-b.x, xki.x, accr[t]);
+                  acci[t] = fma(a.x, xki.x, acci[t]); acci[t] = fma(b.x, xk.x, acci[t]);
+                  accr[t] = fma(a.y, xk.y, accr[t]);  accr[t] = fma(-b.y, xki.y, accr[t]);
+                  acci[t] = fma(a.y, xki.y, acci[t]); acci[t] = fma(b.y, xk.y, acci[t]);
+                } else {
+                  a.x = fma(-vpr[t], wk.x, a.x);  a.x = fma(-wpr[t], vk.x, a.x);
+                  a.y = fma(-vpr[t], wk.y, a.y);  a.y = fma(-wpr[t], vk.y, a.y);
+                  accr[t] = fma(a.x, xk.x, accr[t]);
+                  accr[t] = fma(a.y, xk.y, accr[t]);
+                }
+                ar[t][c] = a;
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < RR; ++t) {
+          const int i = first_res + g + NW * t;
+          if (i < n && i > j) {                            // wave-uniform
+            const double yr = trd_wave_sum(accr[t]);
+            const double yi = CPLX ? trd_wave_sum(acci[t]) : 0.0;
+            const double pr = tr * yr - ti * yi, pi = tr * yi + ti * yr;
+            const double vr = bX[0][i], vi = CPLX ? bX[1][i] : 0.0;
+            if (lane == 0) {
+              trd_st_sc1(S.pub[cur][0] + i, pr);
+              if (CPLX) trd_st_sc1(S.pub[cur][1] + i, pi);
+            }
+            gwr += pr * vr + pi * vi;
+            gwi += pr * vi - pi * vr;
+            if (i == j + 1) {                              // the next column's row: publish it as stored (update j applied next time)
+#pragma unroll
+              for (int c = 0; c < NC; ++c) {
+                if (c >= c0) {
+                  const int k = 128 * c + 2 * lane;
+                  trd_st_sc1(S.rowbuf[prev][0] + k, ar[t][c].x);
+                  trd_st_sc1(S.rowbuf[prev][0] + k + 1, ar[t][c].y);
+                  if (CPLX) {
+                    trd_st_sc1(S.rowbuf[prev][1] + k, ai[t][c].x);
+                    trd_st_sc1(S.rowbuf[prev][1] + k + 1, ai[t][c].y);
+                  }
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+    // early rows (i < first_res, owner wave i mod NW): the same from global memory
+    {
+      int i = g;
+      if (i < j + 1) i += ((j + 1 - i + NW - 1) / NW) * NW;
+      for (; i < first_res; i += NW) {
+        const double svr_ = bV[0][i], swr_ = bW[0][i];
+        const double svi_ = CPLX ? bV[1][i] : 0.0, swi_ = CPLX ? bW[1][i] : 0.0;
+        double* rowr = P.Ar + (int64_t)i * P.ld;
+        double* rowi = CPLX ? P.Ai + (int64_t)i * P.ld : nullptr;
+        double sr = 0.0, si = 0.0;
+        const bool pubrow = i == j + 1;
+        for (int k = 128 * c0 + 2 * lane; k < LV; k += 128) {
+          double2 a = *reinterpret_cast<const double2*>(rowr + k);
+          const double2 wk = *reinterpret_cast<const double2*>(bW[0] + k);
+          const double2 vk = *reinterpret_cast<const double2*>(bV[0] + k);
+          const double2 xk = *reinterpret_cast<const double2*>(bX[0] + k);
+          if (CPLX) {
+            double2 b = *reinterpret_cast<const double2*>(rowi + k);
+            const double2 wki = *reinterpret_cast<const double2*>(bW[1] + k);
+            const double2 vki = *reinterpret_cast<const double2*>(bV[1] + k);
+            const double2 xki = *reinterpret_cast<const double2*>(bX[1] + k);
+            a.x -= (svr_ * wk.x + svi_ * wki.x) + (swr_ * vk.x + swi_ * vki.x);
+            b.x -= (svi_ * wk.x - svr_ * wki.x) + (swi_ * vk.x - swr_ * vki.x);
+            a.y -= (svr_ * wk.y + svi_ * wki.y) + (swr_ * vk.y + swi_ * vki.y);
+            b.y -= (svi_ * wk.y - svr_ * wki.y) + (swi_ * vk.y - swr_ * vki.y);
+            *reinterpret_cast<double2*>(rowr + k) = a;
+            *reinterpret_cast<double2*>(rowi + k) = b;
+            sr += a.x * xk.x - b.x * xki.x;
+            si += a.x * xki.x + b.x * xk.x;
+            sr += a.y * xk.y - b.y * xki.y;
+            si += a.y * xki.y + b.y * xk.y;
+            if (pubrow) {
+              trd_st_sc1(S.rowbuf[prev][1] + k, b.x);
+              trd_st_sc1(S.rowbuf[prev][1] + k + 1, b.y);
+            }
+          } else {
+            a.x -= svr_ * wk.x + swr_ * vk.x;
+            a.y -= svr_ * wk.y + swr_ * vk.y;
+            *reinterpret_cast<double2*>(rowr + k) = a;
+            sr += a.x * xk.x;
+            sr += a.y * xk.y;
+          }
+          if (pubrow) {
+            trd_st_sc1(S.rowbuf[prev][0] + k, a.x);
+            trd_st_sc1(S.rowbuf[prev][0] + k + 1, a.y);
+          }
+        }
+        const double yr = trd_wave_sum(sr);
+        const double yi = CPLX ? trd_wave_sum(si) : 0.0;
+        const double pr = tr * yr - ti * yi, pi = tr * yi + ti * yr;
+        const double vr = bX[0][i], vi = CPLX ? bX[1][i] : 0.0;
+        if (lane == 0) {
+          trd_st_sc1(S.pub[cur][0] + i, pr);
+          if (CPLX) trd_st_sc1(S.pub[cur][1] + i, pi);
+        }
+        gwr += pr * vr + pi * vi;
+        gwi += pr * vi - pi * vr;
+      }
+    }
+    if (prof) P.prof[8 * j + 4] = __builtin_amdgcn_s_memtime();
+    if (lane == 0) {
+      gam_sh[wave][0] = gwr;
+      gam_sh[wave][1] = gwi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double sr = 0.0, si = 0.0;
+#pragma unroll
+      for (int w = 0; w < TRD_RES_THREADS / 64; ++w) { sr += gam_sh[w][0]; si += gam_sh[w][1]; }
+      trd_st_sc1(S.gpart[cur][0] + blockIdx.x, sr);
+      if (CPLX) trd_st_sc1(S.gpart[cur][1] + blockIdx.x, si);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every storing wave drains before the flag goes out
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(S.flags + blockIdx.x, (unsigned int)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prof) P.prof[8 * j + 5] = __builtin_amdgcn_s_memtime();
+    // ---- exchange: wait until every workgroup has published column j ----
+    if (wave == 0) {
+      unsigned int spins = 0;
+      for (;;) {
+        bool ok = true;
+        for (int w = lane; w < nwg; w += 64)
+          ok &= __hip_atomic_load(S.flags + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned int)(j + 1);
+        if (__all(ok)) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 21)) { if (lane == 0) give_up_sh = 1; break; }     // a workgroup is missing: report, never hang
+      }
+    }
+    __syncthreads();
+    if (prof) P.prof[8 * j + 6] = __builtin_amdgcn_s_memtime();
+    if (give_up_sh) {
+      if (tid == 0) atomicExch(S.give_up, 1);
+      break;
+    }
+    // v_j becomes v_{j-1}
+    { double* t0 = bV[0]; bV[0] = bX[0]; bX[0] = t0; }
+    if (CPLX) { double* t1 = bV[1]; bV[1] = bX[1]; bX[1] = t1; }
+    tpr = tr;
+    tpi = ti;
   }
 }
 
@@ -335,7 +818,7 @@ __global__ void trd_copy_kernel(const double* __restrict__ Ar, const double* __r
 // lam_desc[n-1-k] = eigenvalue k (ascending) / scale factor.  flag[0] != 0: non-finite input.
 constexpr int TRD_BIS_THREADS = 256;
 __global__ __launch_bounds__(TRD_BIS_THREADS) void trd_bisect_kernel(const double* __restrict__ d, const double* __restrict__ e, int n,
-                                                                   const double* __restrict__ scal, double* lam_desc, int* flag) {
+                                                                   const double* __restrict__ scal, double* lam_desc, double* lam_asc_scaled, int* flag) {
   extern __shared__ __attribute__((aligned(16))) double bis_lds[];
   __shared__ double red[2][TRD_BIS_THREADS / 64];
   double* sd = bis_lds;
@@ -398,7 +881,10 @@ __global__ __launch_bounds__(TRD_BIS_THREADS) void trd_bisect_kernel(const doubl
     if (s > 0) lo = x_lo;
     if (s < 16) hi = x_hi;
   }
-  if (live && l == 0) lam_desc[n - 1 - k] = 0.5 * (lo + hi) / scal[0];
+  if (live && l == 0) {
+    lam_desc[n - 1 - k] = 0.5 * (lo + hi) / scal[0];
+    if (lam_asc_scaled) lam_asc_scaled[k] = 0.5 * (lo + hi);
+  }
 }
 
 struct TrdWorkspace {
@@ -407,6 +893,10 @@ struct TrdWorkspace {
   DevBuf<double> vec;         // vb, pb, gp, tau, d, e
   DevBuf<double> scal;
   DevBuf<int> flag;
+  DevBuf<unsigned long long> prof;   // (XMCA_TRD_PROF=file) s_memtime stamps
+  DevBuf<double> sync;               // exchange buffers of the resident kernel
+  DevBuf<unsigned int> flags;
+  int resident_used = 0;             // 1: the last reduction ran as the persistent resident kernel, 2: it gave up and was repeated
   double ms = 0.0;            // (profiling: accumulated device time of the reduction, when measured)
 };
 
@@ -419,7 +909,7 @@ inline bool trd_enabled() {
 inline size_t trd_step_lds(int n, bool cplx) { return (size_t)(((n + 3) + 1) & ~1) * 3 * (cplx ? 2 : 1) * sizeof(double); }
 
 inline bool trd_fits(int n, bool cplx) {
-  return trd_step_lds(n, cplx) + 8192 <= (size_t)160 * 1024 && n <= TRD_ROWS * TRD_MAX_WGS * TRD_MAX_ITERS && (size_t)n * 16 <= (size_t)150 * 1024;
+  return trd_step_lds(n, cplx) + 8192 <= (size_t)160 * 1024 && n + 4 <= 16 * TRD_THREADS && (size_t)n * 16 <= (size_t)150 * 1024;
 }
 
 struct TrdLayout {
@@ -438,16 +928,34 @@ struct TrdLayout {
     P.d = p; p += nv;
     P.e = p; p += nv;
     P.Vr = Vr; P.Vi = Vi;
+    P.prof = nullptr;
     return P;
   }
   static size_t doubles(size_t nv) { return nv * 12 + (size_t)TRD_MAX_WGS * 8; }
 };
 
+inline std::mutex& trd_resident_mutex() {
+  static std::mutex* m = new std::mutex;
+  return *m;
+}
+
+// resident form: chunks of 128 columns per row (NC) and rows per wave (RR) by problem kind; 0 = does not fit
+inline int trd_resident_nc(int n, bool cplx) {
+  static const int min_n = [] { const char* e = std::getenv("XMCA_TRD_RESIDENT_MIN_N"); return e ? std::atoi(e) : 384; }();
+  static const bool on = [] { const char* e = std::getenv("XMCA_TRD_RESIDENT"); return !(e && e[0] == '0'); }();
+  if (!on || n < min_n) return 0;
+  if (n <= 8 * 128) return 8;
+  if (n <= 16 * 128) return 16;
+  if (cplx) return n <= 20 * 128 ? 20 : 0;
+  return n <= 24 * 128 ? 24 : 0;
+}
+
 // Reduces the Hermitian matrix (Ar, Ai) to tridiagonal form on `st`.  Afterwards P.d / P.e hold the tridiagonal of
 // f * A (f = ws.scal[0]), P.tau and (keep_reflectors) ws.V the reflectors.  Returns the parameter block.
 inline TrdParams trd_reduce(hipStream_t st, TrdWorkspace& ws, const double* Ar, const double* Ai, int n, int64_t lda, bool keep_reflectors) {
   const bool cplx = Ai != nullptr;
-  const int64_t ld = ((int64_t)n + 2 + 15) & ~(int64_t)15;
+  const int nc = trd_resident_nc(n, cplx);
+  const int64_t ld = std::max<int64_t>(((int64_t)n + 2 + 15) & ~(int64_t)15, (int64_t)nc * 128);
   const size_t nv = (size_t)((n + 8 + 15) & ~15);
   ws.W[0].ensure((size_t)n * ld);
   if (cplx) ws.W[1].ensure((size_t)n * ld);
@@ -469,31 +977,123 @@ inline TrdParams trd_reduce(hipStream_t st, TrdWorkspace& ws, const double* Ar, 
                            (keep_reflectors && cplx) ? ws.V[1].get() : nullptr);
   hipLaunchKernelGGL(trd_maxdiag_kernel, dim3(1), dim3(256), 0, st, Ar, n, lda, ws.scal.get());
   hipLaunchKernelGGL(trd_copy_kernel, dim3(n), dim3(256), 0, st, Ar, Ai, n, lda, P.Ar, P.Ai, ld, ws.scal.get());
+  ws.resident_used = 0;
+
+  // ---- persistent form: the trailing matrix in registers, one exchange per column ----
+  if (nc > 0) {
+    static const int n_cus = [] {
+      int dev = 0, v = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
+      return v > 0 ? v : 256;
+    }();
+    const int rr = cplx ? 2 : 4;
+    const int wgs = std::max(1, std::min(std::min(n_cus, TRD_MAX_WGS), ceil_div(n, (TRD_RES_THREADS / 64) * rr)));
+    const int first_res = std::max(0, n - wgs * (TRD_RES_THREADS / 64) * rr);
+    const size_t lv = (size_t)nc * 128;
+    const size_t sync_doubles = 4 * nv + 4 * (size_t)TRD_MAX_WGS + 4 * lv;
+    ws.sync.ensure(sync_doubles);
+    ws.flags.ensure(TRD_MAX_WGS + 4);
+    XMCA_HIP(hipMemsetAsync(ws.sync.get(), 0, sizeof(double) * sync_doubles, st));
+    XMCA_HIP(hipMemsetAsync(ws.flags.get(), 0, sizeof(unsigned int) * (TRD_MAX_WGS + 4), st));
+    TrdSync S{};
+    double* q = ws.sync.get();
+    for (int a = 0; a < 2; ++a) for (int c = 0; c < 2; ++c) { S.pub[a][c] = q; q += nv; }
+    for (int a = 0; a < 2; ++a) for (int c = 0; c < 2; ++c) { S.gpart[a][c] = q; q += TRD_MAX_WGS; }
+    for (int a = 0; a < 2; ++a) for (int c = 0; c < 2; ++c) { S.rowbuf[a][c] = q; q += lv; }
+    S.flags = ws.flags.get();
+    S.give_up = reinterpret_cast<int*>(ws.flags.get() + TRD_MAX_WGS);
+    using ResFn = void (*)(TrdParams, TrdSync, int);
+    ResFn fn = nullptr;
+    if (cplx) fn = nc == 8 ? trd_resident_kernel<true, 8, 2> : nc == 16 ? trd_resident_kernel<true, 16, 2> : trd_resident_kernel<true, 20, 2>;
+    else fn = nc == 8 ? trd_resident_kernel<false, 8, 4> : nc == 16 ? trd_resident_kernel<false, 16, 4> : trd_resident_kernel<false, 24, 4>;
+    const size_t lds = lv * 3 * (cplx ? 2 : 1) * sizeof(double);
+    XMCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    static const char* prof_file_r = std::getenv("XMCA_TRD_PROF");
+    if (prof_file_r) {
+      P.prof = ws.prof.ensure((size_t)8 * n);
+      XMCA_HIP(hipMemsetAsync(P.prof, 0, sizeof(unsigned long long) * 8 * (size_t)n, st));
+    }
+    int gave_up = 0;
+    {
+      // one persistent grid at a time per process: two of them (two surrogate lanes) could each hold a part of the CUs
+      // and wait for the rest forever (bounded here, but slow)
+      std::lock_guard<std::mutex> lock(trd_resident_mutex());
+      hipLaunchKernelGGL(fn, dim3(wgs), dim3(TRD_RES_THREADS), lds, st, P, S, first_res);
+      XMCA_HIP(hipGetLastError());
+      XMCA_HIP(hipMemcpyAsync(&gave_up, S.give_up, sizeof(int), hipMemcpyDeviceToHost, st));
+      XMCA_HIP(hipStreamSynchronize(st));
+    }
+    if (prof_file_r) {
+      std::vector<unsigned long long> hp((size_t)8 * n);
+      XMCA_HIP(hipMemcpy(hp.data(), P.prof, sizeof(unsigned long long) * hp.size(), hipMemcpyDeviceToHost));
+      if (FILE* f = std::fopen(prof_file_r, "w")) {
+        for (int j = 0; j < n; ++j) {
+          for (int q = 0; q < 7; ++q) std::fprintf(f, "%llu ", hp[(size_t)8 * j + q] - (q ? hp[(size_t)8 * j] : (j ? hp[(size_t)8 * (j - 1)] : hp[0])));
+          std::fprintf(f, "\n");
+        }
+        std::fclose(f);
+      }
+      P.prof = nullptr;
+    }
+    if (!gave_up) {
+      ws.resident_used = 1;
+      return P;
+    }
+    // a workgroup never became resident (another process holds CUs?): start again with one launch per column
+    ws.resident_used = 2;
+    hipLaunchKernelGGL(trd_copy_kernel, dim3(n), dim3(256), 0, st, Ar, Ai, n, lda, P.Ar, P.Ai, ld, ws.scal.get());
+    XMCA_HIP(hipMemsetAsync(ws.vec.get(), 0, sizeof(double) * TrdLayout::doubles(nv), st));
+    if (keep_reflectors) {
+      XMCA_HIP(hipMemsetAsync(ws.V[0].get(), 0, sizeof(double) * (size_t)n * ld, st));
+      if (cplx) XMCA_HIP(hipMemsetAsync(ws.V[1].get(), 0, sizeof(double) * (size_t)n * ld, st));
+    }
+  }
+
   const size_t lds = trd_step_lds(n, cplx);
-  if (cplx)
-    XMCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trd_step_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-  else
-    XMCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trd_step_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  const int slots = ((n + 3) + 1) & ~1;
+  const int ns = slots <= 2 * TRD_THREADS ? 2 : slots <= 4 * TRD_THREADS ? 4 : slots <= 8 * TRD_THREADS ? 8 : 16;
+  using StepFn = void (*)(TrdParams, int, int);
+  StepFn fn = nullptr;
+  XMCA_CHECK(!cplx || ns <= 8, XMCA_ERR_UNSUPPORTED, "trd_reduce: complex problem too large for the LDS of a workgroup");   // (trd_fits)
+  if (cplx) fn = ns == 2 ? trd_step_kernel<true, 2> : ns == 4 ? trd_step_kernel<true, 4> : trd_step_kernel<true, 8>;
+  else fn = ns == 2 ? trd_step_kernel<false, 2> : ns == 4 ? trd_step_kernel<false, 4> : ns == 8 ? trd_step_kernel<false, 8> : trd_step_kernel<false, 16>;
+  XMCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  static const char* prof_file = std::getenv("XMCA_TRD_PROF");     // experiments: phase stamps of workgroup 0, one line per launch
+  if (prof_file) {
+    P.prof = ws.prof.ensure((size_t)8 * n);
+    XMCA_HIP(hipMemsetAsync(P.prof, 0, sizeof(unsigned long long) * 8 * (size_t)n, st));
+  }
   int wgs_prev = 1;
   for (int j = 0; j < n; ++j) {
     const int m = n - j - 1;
     const int wgs = std::max(1, std::min(TRD_MAX_WGS, (m + TRD_ROWS - 1) / TRD_ROWS));
-    if (cplx) hipLaunchKernelGGL(trd_step_kernel<true>, dim3(wgs), dim3(TRD_THREADS), lds, st, P, j, wgs_prev);
-    else hipLaunchKernelGGL(trd_step_kernel<false>, dim3(wgs), dim3(TRD_THREADS), lds, st, P, j, wgs_prev);
+    hipLaunchKernelGGL(fn, dim3(wgs), dim3(TRD_THREADS), lds, st, P, j, wgs_prev);
     wgs_prev = wgs;
   }
   XMCA_HIP(hipGetLastError());
+  if (prof_file) {
+    std::vector<unsigned long long> hp((size_t)8 * n);
+    XMCA_HIP(hipMemcpyAsync(hp.data(), P.prof, sizeof(unsigned long long) * hp.size(), hipMemcpyDeviceToHost, st));
+    XMCA_HIP(hipStreamSynchronize(st));
+    if (FILE* f = std::fopen(prof_file, "w")) {
+      for (int j = 0; j < n; ++j) {
+        for (int q = 0; q < 7; ++q) std::fprintf(f, "%llu ", hp[(size_t)8 * j + q] - (q ? hp[(size_t)8 * j] : 0ull));
+        std::fprintf(f, "\n");
+      }
+      std::fclose(f);
+    }
+  }
   return P;
 }
 
 // all eigenvalues, descending, into lam_dev (device, n doubles; may be nullptr) and lam_host.  Synchronises `st`.
 inline void trd_eigenvalues(hipStream_t st, TrdWorkspace& ws, const TrdParams& P, std::vector<double>& lam_host, double* lam_dev,
-                            DevBuf<double>& lam_tmp) {
+                            DevBuf<double>& lam_tmp, double* lam_asc_scaled = nullptr) {
   const int n = P.n;
   double* out = lam_dev ? lam_dev : lam_tmp.ensure((size_t)n);
   XMCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trd_bisect_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   hipLaunchKernelGGL(trd_bisect_kernel, dim3(ceil_div(n, TRD_BIS_THREADS / 16)), dim3(TRD_BIS_THREADS), sizeof(double) * 2 * (size_t)n, st, P.d,
-                     P.e, n, ws.scal.get(), out, ws.flag.get());
+                     P.e, n, ws.scal.get(), out, lam_asc_scaled, ws.flag.get());
   XMCA_HIP(hipGetLastError());
   lam_host.resize((size_t)n);
   int flag = 0;
