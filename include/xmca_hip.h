@@ -132,7 +132,8 @@ int xmca_bootstrap_runs(xmca_handle* h, const double* hilbert_col, const int64_t
 int xmca_is_complex(xmca_handle* h);
 /* Diagnostics of the last solve: for each of the up to three eigen-decompositions (left Gram, right Gram, kernel):
  * info[3*i + 0] = outer sweeps, info[3*i + 1] = tile size, info[3*i + 2] = pair slots (i = 0..2), then
- * info[9 + i] = 1 when the eigensolver inserted a Cholesky LR step (graded spectrum).  n <= 12. */
+ * info[9 + i]: bit 0 = the eigensolver inserted a Cholesky LR step (graded spectrum), bit 1 = the problem was solved by
+ * reduction to tridiagonal form (csrc/tridiag.h: then no sweeps, tile and slots are 0).  n <= 12. */
 int xmca_get_solve_info(xmca_handle* h, int* info, int n);
 
 /* promax / varimax of xmca/tools/rotation.py:84-149, :15-78 on a host loading matrix L (N x p row-major,

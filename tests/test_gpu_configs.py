@@ -116,7 +116,8 @@ def test_c3_at_full_size_matches_reference():
         assert np.max(np.abs(G - np.eye(2500)[sel])) < 1e-6, key
     info = m._device().solve_info()
     if os.environ.get("XMCA_CHOLESKY_FACTOR", "1") != "0":
-        assert info[0]["sweeps"] == 0 and info[2]["sweeps"] > 0      # no eigen-decomposition of the first field (Cholesky factor)
+        # no eigen-decomposition of the first field (Cholesky factor); the kernel's by Jacobi sweeps or by tridiagonalisation
+        assert info[0]["sweeps"] == 0 and not info[0]["tridiag"] and (info[2]["sweeps"] > 0 or info[2]["tridiag"])
 
 
 def test_real_model_at_c3_size_matches_reference():
@@ -189,10 +190,14 @@ def _check_config(gold, name, cplx, n_rot, power, preprocess):
     return m
 
 
+@pytest.mark.parametrize("tridiag", [True, False])
 @pytest.mark.parametrize("n,cplx", [(2920, False), (2501, True)])
-def test_eigh_at_config_size_matches_lapack(hip, n, cplx):
+def test_eigh_at_config_size_matches_lapack(hip, n, cplx, tridiag, monkeypatch):
     """The T x T eigenproblems of C2 (n = 2920, real) and of C3's analytic-signal subspace (n = T/2 + 1 = 2501, complex
-    Hermitian) at full size: all eigenvalues against numpy.linalg.eigvalsh, orthonormal vectors, residuals."""
+    Hermitian) at full size: all eigenvalues against numpy.linalg.eigvalsh, orthonormal vectors, residuals - by both
+    eigensolvers of the library: reduction to tridiagonal form (csrc/tridiag.h, the default at this size) and the block
+    Jacobi sweeps (csrc/jacobi.h, XMCA_TRIDIAG=0)."""
+    monkeypatch.setenv("XMCA_TRIDIAG", "1" if tridiag else "0")
     rng = np.random.default_rng(n)
     N = 3 * n
     X = (rng.standard_normal((n, 20)) * np.linspace(10, 1, 20)) @ rng.standard_normal((20, N)) + rng.standard_normal((n, N))
@@ -203,7 +208,10 @@ def test_eigh_at_config_size_matches_lapack(hip, n, cplx):
     lam, U = hip.eigh(G)
     ref = np.linalg.eigvalsh(G)[::-1]
     assert np.max(np.abs(lam - ref)) < 1e-11 * ref[0], hip.last_eigh_info
-    assert hip.last_eigh_info["sweeps"] <= 20 and hip.last_eigh_info["slots"] == -(-n // hip.last_eigh_info["tile"])
+    if tridiag:
+        assert hip.last_eigh_info["tridiag"] == 1 and hip.last_eigh_info["sweeps"] == 0
+    else:
+        assert hip.last_eigh_info["sweeps"] <= 20 and hip.last_eigh_info["slots"] == -(-n // hip.last_eigh_info["tile"])
     sel = np.r_[0:40, n // 2:n // 2 + 40, n - 40:n]                   # leading, bulk and trailing (null: centered) vectors
     Us = U[:, sel]
     assert np.max(np.abs(Us.conj().T @ U - np.eye(n)[sel])) < 1e-11

@@ -97,7 +97,7 @@ def test_eigh_rank_deficient_complex(hip):
 
 
 @pytest.mark.parametrize("n,cplx,decades", [(700, False, 10), (500, True, 8), (1000, False, 6)])
-def test_eigh_graded_spectrum_takes_the_cholesky_lr_step(hip, n, cplx, decades):
+def test_eigh_graded_spectrum_takes_the_cholesky_lr_step(hip, n, cplx, decades, monkeypatch):
     """Eigenvalues spread evenly over many decades: the solver inserts one Cholesky LR step (jacobi.h) and
     must still return orthonormal vectors - also for the small eigenvalues, which the back-transformation R^H v
     only gives if the sweeps converge relative to sqrt(m_ii m_jj)."""
@@ -107,6 +107,7 @@ def test_eigh_graded_spectrum_takes_the_cholesky_lr_step(hip, n, cplx, decades):
     lam_true = np.logspace(0, -decades, n)
     G = (Q * lam_true) @ Q.conj().T
     G = (G + G.conj().T) / 2
+    monkeypatch.setenv("XMCA_TRIDIAG", "0")            # (the Jacobi solver; the tridiagonal route: tests/test_gpu_tridiag.py)
     lam, U = hip.eigh(G)
     assert hip.last_eigh_info["lr_step"] == 1, hip.last_eigh_info
     ref = np.linalg.eigvalsh(G)[::-1]

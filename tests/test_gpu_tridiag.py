@@ -1,0 +1,120 @@
+"""The second eigensolver of the library: Householder reduction to tridiagonal form + Sturm multisection (+ twisted
+factorisation vectors, blocked back-transformation, Newton-Schulz clean-up) - csrc/tridiag.h, csrc/tridiag_vec.h - which
+replaces LAPACK's *gesdd / eigh on the T x T stage of xmca/array.py:479 and :570 for eigenproblems of 192 (values only) /
+768 (with vectors) and more.  Everything against numpy.linalg.eigh / eigvalsh on the same matrices:
+
+* both forms of the reduction - one launch per column, and the persistent kernel with the matrix resident in registers -
+  real and complex, sizes around the chunk / row-slot boundaries of the kernels;
+* spectra the twisted vectors cannot resolve (repeated eigenvalues, wide null spaces) come back through the Jacobi sweeps;
+* bit-reproducibility (every sum has a fixed order) and NaN input -> LinAlgError like gesdd.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _gram(n, cplx, seed=None, spikes=20):
+    rng = np.random.default_rng(n if seed is None else seed)
+    N = 3 * n
+    X = (rng.standard_normal((n, spikes)) * np.linspace(10, 1, spikes)) @ rng.standard_normal((spikes, N)) + rng.standard_normal((n, N))
+    if cplx:
+        X = X + 1j * rng.standard_normal((n, N))
+    X -= X.mean(axis=0)
+    return X @ X.conj().T
+
+
+@pytest.mark.parametrize("resident", ["1", "0"])
+@pytest.mark.parametrize("n,cplx", [(2, False), (3, True), (64, False), (127, True), (129, False), (385, False), (512, True), (1000, False),
+                                    (1025, True), (1100, False), (2049, False), (2100, True)])
+def test_eigenvalues_only_match_lapack(hip, monkeypatch, n, cplx, resident):
+    monkeypatch.setenv("XMCA_TRIDIAG_MIN_N", "2")
+    monkeypatch.setenv("XMCA_TRD_RESIDENT", resident)
+    monkeypatch.setenv("XMCA_TRD_RESIDENT_MIN_N", "2")
+    G = _gram(n, cplx)
+    lam, U = hip.eigh(G, vectors=False)
+    assert U is None and hip.last_eigh_info["tridiag"] == 1 and hip.last_eigh_info["sweeps"] == 0
+    ref = np.linalg.eigvalsh(G)[::-1]
+    assert np.max(np.abs(lam - ref)) < 1e-13 * ref[0]
+    again, _ = hip.eigh(G, vectors=False)
+    assert np.array_equal(lam, again)                       # fixed summation order: the same bits
+
+
+@pytest.mark.parametrize("resident", ["1", "0"])
+@pytest.mark.parametrize("n,cplx", [(70, False), (200, True), (777, False), (1000, True), (1500, False)])
+def test_eigenvectors_match_lapack(hip, monkeypatch, n, cplx, resident):
+    monkeypatch.setenv("XMCA_TRIDIAG_VEC_MIN_N", "2")
+    monkeypatch.setenv("XMCA_TRD_RESIDENT", resident)
+    monkeypatch.setenv("XMCA_TRD_RESIDENT_MIN_N", "2")
+    G = _gram(n, cplx)
+    lam, U = hip.eigh(G)
+    assert hip.last_eigh_info["tridiag"] == 1
+    ref, Uref = np.linalg.eigh(G)
+    ref, Uref = ref[::-1], Uref[:, ::-1]
+    assert np.max(np.abs(lam - ref)) < 1e-13 * ref[0]
+    assert np.max(np.abs(U.conj().T @ U - np.eye(n))) < 1e-12
+    assert np.max(np.linalg.norm(G @ U - U * lam, axis=0)) < 1e-12 * ref[0]
+    # the well separated leading vectors up to phase
+    ov = np.abs(np.sum(U[:, :10].conj() * Uref[:, :10], axis=0))
+    assert np.all(np.abs(ov - 1) < 1e-9)
+
+
+@pytest.mark.parametrize("kind", ["graded12", "lowrank", "identity", "diagonal", "two_clusters", "tridiagonal_input"])
+def test_hard_spectra_with_vectors(hip, monkeypatch, kind):
+    """graded / already diagonal / already tridiagonal matrices stay on the tridiagonal route; repeated eigenvalues and wide
+    null spaces - where twisted-factorisation vectors of one cluster are not independent - must be detected
+    (max |Z^H Z - I| > 0.3) and come back through the Jacobi sweeps.  Either way the result is a full decomposition."""
+    monkeypatch.setenv("XMCA_TRIDIAG_VEC_MIN_N", "2")
+    n = 600
+    rng = np.random.default_rng(5)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    if kind == "graded12":
+        G = (Q * np.logspace(0, -12, n)) @ Q.T
+    elif kind == "lowrank":
+        Y = rng.standard_normal((n, 20))
+        G = Y @ Y.T
+    elif kind == "identity":
+        G = np.eye(n)
+    elif kind == "diagonal":
+        G = np.diag(np.arange(1.0, n + 1))
+    elif kind == "two_clusters":
+        G = (Q * np.r_[np.full(n // 2, 2.0), np.full(n - n // 2, 1.0)]) @ Q.T
+    else:
+        G = np.diag(rng.standard_normal(n)) + np.diag(rng.standard_normal(n - 1), 1)
+        G = G + G.T
+    G = (G + G.T) / 2
+    lam, U = hip.eigh(G)
+    ref = np.linalg.eigvalsh(G)[::-1]
+    sc = np.max(np.abs(ref))
+    assert np.max(np.abs(lam - ref)) < 1e-12 * sc
+    assert np.max(np.abs(U.T @ U - np.eye(n))) < 1e-10
+    assert np.max(np.linalg.norm(G @ U - U * lam, axis=0)) < 1e-10 * sc
+    if kind in ("lowrank", "identity", "two_clusters"):
+        assert hip.last_eigh_info["tridiag"] == 0           # handed to the Jacobi solver
+    else:
+        assert hip.last_eigh_info["tridiag"] == 1
+
+
+def test_nan_input_raises_like_gesdd(hip, monkeypatch):
+    monkeypatch.setenv("XMCA_TRIDIAG_MIN_N", "2")
+    G = _gram(300, False)
+    G[17, 40] = G[40, 17] = np.nan
+    with pytest.raises(np.linalg.LinAlgError):
+        hip.eigh(G, vectors=False)
+    with pytest.raises(np.linalg.LinAlgError):
+        hip.eigh(G)
+
+
+def test_values_of_a_model_do_not_depend_on_the_eigensolver(monkeypatch):
+    """MCA.rule_n without rotation (xmca/array.py:1753-1765) takes eigenvalues only: the tridiagonal route and the Jacobi
+    sweeps must give the same spectra to rounding."""
+    from golden_inputs import make_input
+    from xmca_amd.array import MCA
+    m = MCA(*make_input("c1_standin"))
+    m.solve()
+    monkeypatch.setenv("XMCA_TRIDIAG", "1")
+    a = m.rule_n(3, seed=11)
+    monkeypatch.setenv("XMCA_TRIDIAG", "0")
+    b = m.rule_n(3, seed=11)
+    keep = b > 1e-9 * b[0]
+    assert a.shape == b.shape and np.max(np.abs(a[keep] - b[keep]) / b[keep]) < 1e-9

@@ -247,8 +247,8 @@ class Handle:
     def solve_info(self):
         info = np.zeros(12, dtype=np.int32)
         self._check(self._lib.xmca_get_solve_info(self._h, _ptr(info), 12))
-        return [{"sweeps": int(info[3 * i]), "tile": int(info[3 * i + 1]), "slots": int(info[3 * i + 2]), "lr_step": int(info[9 + i])}
-                for i in range(3)]
+        return [{"sweeps": int(info[3 * i]), "tile": int(info[3 * i + 1]), "slots": int(info[3 * i + 2]), "lr_step": int(info[9 + i]) & 1,
+                 "tridiag": (int(info[9 + i]) >> 1) & 1} for i in range(3)]
 
     def singular_values(self, n):
         out = np.empty(n, dtype=np.float64)

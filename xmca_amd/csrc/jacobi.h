@@ -164,7 +164,7 @@ inline void hermitian_evd(hipStream_t st, EvdWorkspace& ws, const double* Ar, co
                           EvdInfo* info = nullptr, int force_tile = 0) {
   // eigenvalues only (rule_n without rotation, every n_vec = 0 solve): Householder tridiagonalisation + Sturm multisection
   // (tridiag.h) - (4/3) n^3 flop in n launches instead of ~11 sweeps of 4 n^3.  XMCA_TRIDIAG=0 keeps the Jacobi sweeps.
-  static const int trd_min_n = [] { const char* e = std::getenv("XMCA_TRIDIAG_MIN_N"); return e ? std::atoi(e) : 192; }();
+  const int trd_min_n = [] { const char* e = std::getenv("XMCA_TRIDIAG_MIN_N"); return e ? std::atoi(e) : 192; }();
   if (!Zr && trd_enabled() && n >= trd_min_n && trd_fits(n, Ai != nullptr)) {
     TrdParams P = trd_reduce(st, ws.trd, Ar, Ai, n, lda, false);
     trd_eigenvalues(st, ws.trd, P, lam_host, lam_dev, ws.lam_tmp);
@@ -177,7 +177,7 @@ inline void hermitian_evd(hipStream_t st, EvdWorkspace& ws, const double* Ar, co
   // with eigenvectors: the same reduction, twisted-factorisation vectors of the tridiagonal matrix, back-transformation by
   // blocked reflectors and a Newton-Schulz clean-up (tridiag_vec.h).  Spectra with clusters the clean-up cannot repair
   // (repeated eigenvalues, null spaces of dimension > 1) come back here and take the Jacobi sweeps below.
-  static const int trd_vec_min_n = [] { const char* e = std::getenv("XMCA_TRIDIAG_VEC_MIN_N"); return e ? std::atoi(e) : 768; }();
+  const int trd_vec_min_n = [] { const char* e = std::getenv("XMCA_TRIDIAG_VEC_MIN_N"); return e ? std::atoi(e) : 768; }();
   if (Zr && trd_enabled() && n >= trd_vec_min_n && trd_fits(n, Ai != nullptr)) {
     TrdParams P = trd_reduce(st, ws.trd, Ar, Ai, n, lda, true);
     std::vector<double> lam_t;

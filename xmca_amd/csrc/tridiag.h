@@ -900,9 +900,10 @@ struct TrdWorkspace {
   double ms = 0.0;            // (profiling: accumulated device time of the reduction, when measured)
 };
 
+// (the switches are read at every call - a getenv per solve - so that one process can run both routes: tests)
 inline bool trd_enabled() {
-  static const bool on = [] { const char* e = std::getenv("XMCA_TRIDIAG"); return !(e && e[0] == '0'); }();
-  return on;
+  const char* e = std::getenv("XMCA_TRIDIAG");
+  return !(e && e[0] == '0');
 }
 
 // LDS of the step kernel for an n x n problem
@@ -941,8 +942,10 @@ inline std::mutex& trd_resident_mutex() {
 
 // resident form: chunks of 128 columns per row (NC) and rows per wave (RR) by problem kind; 0 = does not fit
 inline int trd_resident_nc(int n, bool cplx) {
-  static const int min_n = [] { const char* e = std::getenv("XMCA_TRD_RESIDENT_MIN_N"); return e ? std::atoi(e) : 384; }();
-  static const bool on = [] { const char* e = std::getenv("XMCA_TRD_RESIDENT"); return !(e && e[0] == '0'); }();
+  const char* em = std::getenv("XMCA_TRD_RESIDENT_MIN_N");
+  const int min_n = em ? std::atoi(em) : 384;
+  const char* eo = std::getenv("XMCA_TRD_RESIDENT");
+  const bool on = !(eo && eo[0] == '0');
   if (!on || n < min_n) return 0;
   if (n <= 8 * 128) return 8;
   if (n <= 16 * 128) return 16;

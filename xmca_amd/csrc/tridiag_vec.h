@@ -5,8 +5,10 @@
 //      z(i+1) = -(e_i / D-_{i+1}) z(i) downwards (Parlett & Dhillon; LAPACK dlar1v without the RRR shifts).  With an
 //      eigenvalue accurate to eps ||T|| the residual is eps ||T||; vectors of close eigenvalues are orthogonal only to
 //      eps ||T|| / gap - the clean-up below restores that;
-//   2. back-transformation with blocks of 64 reflectors in compact WY form, I - V T V^H, all products MFMA GEMMs.  T comes
-//      from its inverse, which is explicit: T^{-1} = striu(V^H V) + diag(1 / tau) (from T^{-1} + T^{-H} = V^H V);
+//   2. back-transformation with blocks of 64 reflectors in compact WY form, Z -= V (T (V^H Z)), the two tall products MFMA
+//      GEMMs.  T is never formed: its inverse is explicit, T^{-1} = striu(V^H V) + diag(1 / tau) (from T^{-1} + T^{-H} =
+//      V^H V), so T W is a back substitution per column (trd_wy_solve_kernel), and V^H V comes out of the same product as
+//      W = V^H Z (the reflectors ride along as 64 extra columns of Z);
 //   3. S = Z^H Z; max |S - I| decides: <= 0.3 -> one or two Newton-Schulz steps Z <- Z (3/2 I - 1/2 S) (the last one
 //      written as (3/2 I - 1/2 S)(rows reversed) Z^H, i.e. straight into the caller's layout: row i = conj(u_i), eigenvalues
 //      descending); otherwise (clusters the twisted vectors cannot resolve: repeated eigenvalues, exact null spaces of
@@ -39,95 +41,155 @@ __global__ __launch_bounds__(64) void trd_twisted_kernel(const double* __restric
   }
   if (!(fabs(dp) >= piv)) dp = dp < 0.0 ? -piv : piv;
   Yt[(int64_t)(n - 1) * ldy + k] = dp;
-  // backward: D- into W, gamma_i = D+_i + D-_i - (d_i - lambda), twist at the smallest |gamma|
+  // backward: D- into W, gamma_i = D+_i + D-_i - (d_i - lambda), twist at the smallest |gamma|.  The loads of D+ do
+  // not depend on the recurrence: eight of them are requested at a time (the loops below are memory-latency bound).
+  constexpr int B = 16;
   double dm = d[n - 1] - l;
   int r = n - 1;
   double gbest = fabs(dp + dm - (d[n - 1] - l));
   if (!(fabs(dm) >= piv)) dm = dm < 0.0 ? -piv : piv;
   W[(int64_t)(n - 1) * ldy + k] = dm;
-  for (int i = n - 2; i >= 0; --i) {
-    const double ei = e[i];
-    dm = (d[i] - l) - (ei / dm) * ei;
-    const double g = fabs(Yt[(int64_t)i * ldy + k] + dm - (d[i] - l));
-    if (g < gbest) { gbest = g; r = i; }
-    if (!(fabs(dm) >= piv)) dm = dm < 0.0 ? -piv : piv;
-    W[(int64_t)i * ldy + k] = dm;
+  for (int i0 = n - 2; i0 >= 0; i0 -= B) {
+    double yp[B];
+#pragma unroll
+    for (int u = 0; u < B; ++u) yp[u] = i0 - u >= 0 ? Yt[(int64_t)(i0 - u) * ldy + k] : 0.0;
+#pragma unroll
+    for (int u = 0; u < B; ++u) {
+      const int i = i0 - u;
+      if (i >= 0) {
+        const double ei = e[i];
+        dm = (d[i] - l) - (ei / dm) * ei;
+        const double g = fabs(yp[u] + dm - (d[i] - l));
+        if (g < gbest) { gbest = g; r = i; }
+        if (!(fabs(dm) >= piv)) dm = dm < 0.0 ? -piv : piv;
+        W[(int64_t)i * ldy + k] = dm;
+      }
+    }
   }
   // the vector
   double z = 1.0, nrm = 1.0;
-  for (int i = r - 1; i >= 0; --i) {
-    z = -(e[i] / Yt[(int64_t)i * ldy + k]) * z;
-    Yt[(int64_t)i * ldy + k] = z;
-    nrm += z * z;
+  for (int i0 = r - 1; i0 >= 0; i0 -= B) {
+    double yp[B];
+#pragma unroll
+    for (int u = 0; u < B; ++u) yp[u] = i0 - u >= 0 ? Yt[(int64_t)(i0 - u) * ldy + k] : 1.0;
+#pragma unroll
+    for (int u = 0; u < B; ++u) {
+      const int i = i0 - u;
+      if (i >= 0) {
+        z = -(e[i] / yp[u]) * z;
+        Yt[(int64_t)i * ldy + k] = z;
+        nrm += z * z;
+      }
+    }
   }
   z = 1.0;
   Yt[(int64_t)r * ldy + k] = 1.0;
-  for (int i = r; i < n - 1; ++i) {
-    z = -(e[i] / W[(int64_t)(i + 1) * ldy + k]) * z;
-    Yt[(int64_t)(i + 1) * ldy + k] = z;
-    nrm += z * z;
+  for (int i0 = r; i0 < n - 1; i0 += B) {
+    double wm[B];
+#pragma unroll
+    for (int u = 0; u < B; ++u) wm[u] = i0 + u < n - 1 ? W[(int64_t)(i0 + u + 1) * ldy + k] : 1.0;
+#pragma unroll
+    for (int u = 0; u < B; ++u) {
+      const int i = i0 + u;
+      if (i < n - 1) {
+        z = -(e[i] / wm[u]) * z;
+        Yt[(int64_t)(i + 1) * ldy + k] = z;
+        nrm += z * z;
+      }
+    }
   }
   const double s = 1.0 / sqrt(nrm);
-  for (int i = 0; i < n; ++i) Yt[(int64_t)i * ldy + k] *= s;
+  for (int i0 = 0; i0 < n; i0 += B) {
+    double y[B];
+#pragma unroll
+    for (int u = 0; u < B; ++u) y[u] = i0 + u < n ? Yt[(int64_t)(i0 + u) * ldy + k] : 0.0;
+#pragma unroll
+    for (int u = 0; u < B; ++u)
+      if (i0 + u < n) Yt[(int64_t)(i0 + u) * ldy + k] = y[u] * s;
+  }
 }
 
-// T = (striu(S) + diag(1 / tau))^{-1} for one block of nb <= 64 reflectors; tau = 0 (identity reflector, zero vector
-// stored): diagonal entry 1.  One thread per row of T.  S, T: nb x nb planes with leading dimension 64.
+// Zext[i][r] = Vs[r][i] (i < mb, r < 64; zero for r >= nb): the block's reflectors as 64 extra columns of Z, so that ONE
+// product V^H [Z | V] gives both W = V^H Z and the Gram matrix V^H V
+__global__ void trd_vcopy_kernel(const double* __restrict__ Vr, const double* __restrict__ Vi, int64_t ldv, int nb, int mb,
+                                 double* __restrict__ Er, double* __restrict__ Ei, int64_t lde) {
+  __shared__ double tr[64][65], ti[64][65];
+  const int i0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;     // 256 threads: 4 rows at a time
+  for (int r = ty; r < 64; r += 4) {
+    const int i = i0 + tx;
+    const bool in = r < nb && i < mb;
+    tr[r][tx] = in ? Vr[(int64_t)r * ldv + i] : 0.0;
+    if (Vi) ti[r][tx] = in ? Vi[(int64_t)r * ldv + i] : 0.0;
+  }
+  __syncthreads();
+  for (int ii = ty; ii < 64; ii += 4) {
+    const int i = i0 + ii;
+    if (i < mb) {
+      Er[(int64_t)i * lde + tx] = tr[tx][ii];
+      if (Vi) Ei[(int64_t)i * lde + tx] = ti[tx][ii];
+    }
+  }
+}
+
+// X = T W for one block of reflectors without forming T: T^{-1} = M = striu(V^H V) + diag(1 / tau) is explicit, so every
+// column of W is back-substituted through M (one thread per column, M in LDS, the column in registers).
+// Wx: 64 x ldw planes; columns [0, n) hold W and are overwritten by X, columns [n, n + 64) hold V^H V.
 template <bool CPLX>
-__global__ __launch_bounds__(64) void trd_tfactor_kernel(const double* __restrict__ Sr, const double* __restrict__ Si,
-                                                         const double* __restrict__ taur, const double* __restrict__ taui, int nb,
-                                                         double* __restrict__ Tr, double* __restrict__ Ti) {
-  extern __shared__ __attribute__((aligned(16))) double tf_lds[];
-  constexpr int LD = 65;
-  double* mr = tf_lds;                  // M = T^{-1}
-  double* qr = mr + 64 * LD;            // T
-  double* mi = qr + 64 * LD;
-  double* qi = mi + (CPLX ? 64 * LD : 0);
-  const int r = threadIdx.x;
-  for (int c = 0; c < 64; ++c) {
+__global__ __launch_bounds__(128) void trd_wy_solve_kernel(double* __restrict__ Wr, double* __restrict__ Wi, int64_t ldw, int n, int nb,
+                                                           const double* __restrict__ taur, const double* __restrict__ taui) {
+  __shared__ double mr[64][64], mi[CPLX ? 64 : 1][64];
+  for (int e = threadIdx.x; e < 64 * 64; e += blockDim.x) {
+    const int r = e >> 6, c = e & 63;
     double a = 0.0, b = 0.0;
     if (r < nb && c < nb) {
       if (c > r) {
-        a = Sr[r * 64 + c];
-        if (CPLX) b = Si[r * 64 + c];
+        a = Wr[(int64_t)r * ldw + n + c];
+        if (CPLX) b = Wi[(int64_t)r * ldw + n + c];
       } else if (c == r) {
-        const double tr = taur[r], ti = CPLX ? taui[r] : 0.0;
-        const double den = tr * tr + ti * ti;
-        if (den > 0.0) { a = tr / den; b = -ti / den; } else { a = 1.0; }
+        // the diagonal holds 1 / M_rr = tau_r (tau = 0: the stored reflector is the zero vector, any finite value does)
+        a = taur[r];
+        if (CPLX) b = taui[r];
       }
-    } else if (r == c) {
-      a = 1.0;
     }
-    mr[r * LD + c] = a;
-    qr[r * LD + c] = 0.0;
-    if (CPLX) { mi[r * LD + c] = b; qi[r * LD + c] = 0.0; }
+    mr[r][c] = a;
+    if (CPLX) mi[r][c] = b;
   }
   __syncthreads();
-  // row r of T: T[r][r] = 1 / M[r][r],  T[r][c] = -(sum_{l=r}^{c-1} T[r][l] M[l][c]) / M[c][c]
-  for (int c = r; c < 64; ++c) {
-    double sr = 0.0, si = 0.0;
-    if (c == r) {
-      sr = -1.0;
-    } else {
-      for (int l = r; l < c; ++l) {
-        const double tr = qr[r * LD + l], m_r = mr[l * LD + c];
-        if (CPLX) {
-          const double ti = qi[r * LD + l], m_i = mi[l * LD + c];
-          sr += tr * m_r - ti * m_i;
-          si += tr * m_i + ti * m_r;
-        } else {
-          sr += tr * m_r;
-        }
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  double xr[64], xi[CPLX ? 64 : 1];
+#pragma unroll
+  for (int r = 0; r < 64; ++r) {
+    xr[r] = r < nb ? Wr[(int64_t)r * ldw + k] : 0.0;
+    if (CPLX) xi[r] = r < nb ? Wi[(int64_t)r * ldw + k] : 0.0;
+  }
+#pragma unroll
+  for (int r = 63; r >= 0; --r) {
+    double sr = xr[r], si = CPLX ? xi[r] : 0.0;
+#pragma unroll
+    for (int l = r + 1; l < 64; ++l) {
+      if (CPLX) {
+        sr -= mr[r][l] * xr[l] - mi[r][l] * xi[l];
+        si -= mr[r][l] * xi[l] + mi[r][l] * xr[l];
+      } else {
+        sr -= mr[r][l] * xr[l];
       }
     }
-    const double dr = mr[c * LD + c], di = CPLX ? mi[c * LD + c] : 0.0, den = dr * dr + di * di;
-    qr[r * LD + c] = -(sr * dr + si * di) / den;
-    if (CPLX) qi[r * LD + c] = -(si * dr - sr * di) / den;
+    // x_r = s / M_rr = s * tau_r
+    if (CPLX) {
+      xr[r] = sr * mr[r][r] - si * mi[r][r];
+      xi[r] = sr * mi[r][r] + si * mr[r][r];
+    } else {
+      xr[r] = sr * mr[r][r];
+    }
   }
-  for (int c = 0; c < 64; ++c) {
-    const bool in = r < nb && c < nb;
-    Tr[r * 64 + c] = in ? qr[r * LD + c] : 0.0;
-    if (CPLX) Ti[r * 64 + c] = in ? qi[r * LD + c] : 0.0;
+#pragma unroll
+  for (int r = 0; r < 64; ++r) {
+    if (r < nb) {
+      Wr[(int64_t)r * ldw + k] = xr[r];
+      if (CPLX) Wi[(int64_t)r * ldw + k] = xi[r];
+    }
   }
 }
 
@@ -173,7 +235,8 @@ struct TrdVecWorkspace {
 inline bool trd_eigenvectors(hipStream_t st, TrdWorkspace& ws, TrdVecWorkspace& vw, GemmWorkspace& gws, const TrdParams& P, bool cplx,
                              double* Zr, double* Zi, int64_t ldz) {
   const int n = P.n;
-  const int64_t ld = P.ld;
+  const int64_t ldv = P.ld;                                   // reflectors
+  const int64_t ld = ((int64_t)n + 64 + 15) & ~(int64_t)15;   // Z with 64 extra columns (the block's reflectors, see trd_vcopy_kernel)
   const size_t plane = (size_t)n * ld;
   double* Yr = vw.Y[0].ensure(plane);
   double* Yi = cplx ? vw.Y[1].ensure(plane) : nullptr;
@@ -182,33 +245,27 @@ inline bool trd_eigenvectors(hipStream_t st, TrdWorkspace& ws, TrdVecWorkspace& 
   hipLaunchKernelGGL(trd_twisted_kernel, dim3(ceil_div(n, 64)), dim3(64), 0, st, P.d, P.e, n, vw.lam_asc.get(), Wr, Yr, ld);
   XMCA_HIP(hipGetLastError());
   if (cplx) XMCA_HIP(hipMemsetAsync(Yi, 0, sizeof(double) * plane, st));
-  // ---- Z = H_0 H_1 ... H_{n-2} Yt, blocks of 64 reflectors from the last to the first ----
-  const size_t small_doubles = 4 * 64 * 64 + 4 * (size_t)64 * ld;
-  double* sm = vw.small.ensure(small_doubles);
-  double* Sbr = sm; double* Sbi = Sbr + 64 * 64; double* Tbr = Sbi + 64 * 64; double* Tbi = Tbr + 64 * 64;
-  double* Wbr = Tbi + 64 * 64; double* Wbi = Wbr + 64 * ld; double* Xbr = Wbi + 64 * ld; double* Xbi = Xbr + 64 * ld;
+  // ---- Z = H_0 H_1 ... H_{n-2} Yt, blocks of 64 reflectors from the last to the first:  Z -= V (T (V^H Z)) ----
+  double* sm = vw.small.ensure(2 * (size_t)64 * ld);
+  double* Wbr = sm; double* Wbi = Wbr + 64 * ld;
   const int nref = n - 1;
-  const size_t tf_lds = sizeof(double) * 64 * 65 * (cplx ? 4 : 2);
-  if (cplx) XMCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trd_tfactor_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-  else XMCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trd_tfactor_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   for (int j0 = ((nref - 1) / 64) * 64; j0 >= 0; j0 -= 64) {
     const int nb = std::min(64, nref - j0);
     const int i0 = j0 + 1, mb = n - i0;                      // support of the block: rows i0 .. n-1
-    const double* Vbr = P.Vr + (int64_t)j0 * ld + i0;        // Vs[r][i - i0], r < nb  (row-major, k fast)
-    const double* Vbi = cplx ? P.Vi + (int64_t)j0 * ld + i0 : nullptr;
-    // S_b = V^H V  (nb x nb):  S[r][c] = sum_i conj(Vs[r][i]) Vs[c][i]
-    cgemm<double>(st, gws, Vbr, Vbi, ld, true, true, Vbr, Vbi, ld, false, false, Sbr, cplx ? Sbi : nullptr, 64, nb, nb, mb, 1.0, nullptr, nullptr, false);
-    if (cplx) hipLaunchKernelGGL(trd_tfactor_kernel<true>, dim3(1), dim3(64), tf_lds, st, Sbr, Sbi, P.tau[0] + j0, P.tau[1] + j0, nb, Tbr, Tbi);
-    else hipLaunchKernelGGL(trd_tfactor_kernel<false>, dim3(1), dim3(64), tf_lds, st, Sbr, nullptr, P.tau[0] + j0, nullptr, nb, Tbr, nullptr);
-    // W_b = V^H Z[i0:, :]  (nb x n)
-    cgemm<double>(st, gws, Vbr, Vbi, ld, true, true, Yr + (int64_t)i0 * ld, cplx ? Yi + (int64_t)i0 * ld : nullptr, ld, true, false, Wbr,
-                  cplx ? Wbi : nullptr, ld, nb, n, mb, 1.0, nullptr, nullptr, false);
-    // X_b = T W_b
-    cgemm<double>(st, gws, Tbr, cplx ? Tbi : nullptr, 64, true, false, Wbr, cplx ? Wbi : nullptr, ld, true, false, Xbr, cplx ? Xbi : nullptr, ld,
-                  nb, n, nb, 1.0, nullptr, nullptr, false);
-    // Z[i0:, :] -= V X_b      (A(m = i, k = r) = Vs[r][i]: the k-slow orientation)
-    cgemm<double>(st, gws, Vbr, Vbi, ld, false, false, Xbr, cplx ? Xbi : nullptr, ld, true, false, Yr + (int64_t)i0 * ld,
-                  cplx ? Yi + (int64_t)i0 * ld : nullptr, ld, mb, n, nb, -1.0, nullptr, nullptr, false, 1.0);
+    const double* Vbr = P.Vr + (int64_t)j0 * ldv + i0;       // Vs[r][i - i0], r < nb  (row-major, k fast)
+    const double* Vbi = cplx ? P.Vi + (int64_t)j0 * ldv + i0 : nullptr;
+    double* Zr0 = Yr + (int64_t)i0 * ld;
+    double* Zi0 = cplx ? Yi + (int64_t)i0 * ld : nullptr;
+    hipLaunchKernelGGL(trd_vcopy_kernel, dim3(ceil_div(mb, 64)), dim3(256), 0, st, Vbr, Vbi, ldv, nb, mb, Zr0 + n, cplx ? Zi0 + n : nullptr, ld);
+    // [W | S] = V^H [Z | V]  (nb x (n + 64)):  W[r][k] = sum_i conj(Vs[r][i]) Z[i][k]
+    cgemm<double>(st, gws, Vbr, Vbi, ldv, true, true, Zr0, Zi0, ld, true, false, Wbr, cplx ? Wbi : nullptr, ld, nb, n + 64, mb, 1.0, nullptr,
+                  nullptr, false);
+    // X = T W, in place
+    if (cplx) hipLaunchKernelGGL(trd_wy_solve_kernel<true>, dim3(ceil_div(n, 128)), dim3(128), 0, st, Wbr, Wbi, ld, n, nb, P.tau[0] + j0, P.tau[1] + j0);
+    else hipLaunchKernelGGL(trd_wy_solve_kernel<false>, dim3(ceil_div(n, 128)), dim3(128), 0, st, Wbr, nullptr, ld, n, nb, P.tau[0] + j0, nullptr);
+    // Z[i0:, :] -= V X      (A(m = i, k = r) = Vs[r][i]: the k-slow orientation)
+    cgemm<double>(st, gws, Vbr, Vbi, ldv, false, false, Wbr, cplx ? Wbi : nullptr, ld, true, false, Zr0, Zi0, ld, mb, n, nb, -1.0, nullptr,
+                  nullptr, false, 1.0);
   }
   XMCA_HIP(hipGetLastError());
   // ---- orthonormality of the result, Newton-Schulz clean-up, transposition into the caller's layout ----

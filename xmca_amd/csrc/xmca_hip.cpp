@@ -805,7 +805,7 @@ int xmca_get_solve_info(xmca_handle* h, int* info, int n) {
     const EvdInfo& e = h->res.evd_info[i / 3];
     info[i] = (i % 3 == 0) ? e.sweeps : (i % 3 == 1) ? e.tile : e.slots;
   }
-  for (int i = 9; i < n && i < 12; ++i) info[i] = h->res.evd_info[i - 9].lr_step;
+  for (int i = 9; i < n && i < 12; ++i) info[i] = h->res.evd_info[i - 9].lr_step + 2 * h->res.evd_info[i - 9].tridiag;   // bit 1: tridiagonal route
   return XMCA_OK;
 }
 
