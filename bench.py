@@ -16,10 +16,11 @@ run-sharded rule_n of configuration C4 (surrogates/s over all ranks).
   `rule_n.surrogates_per_s` (all ranks together).  XMCA_BENCH_SHARE_GPU=1 puts every rank on GPU 0 with the gloo
   backend (RCCL refuses two ranks on one device) - the way the multi-rank flow is exercised on a 1-GPU box.
 * prints ONE JSON line on rank 0 with the driver's contract keys plus
-    `roofline`       the DOMINANT kernel of the step, jacobi_fused_round_kernel (f64 MFMA bound): algorithmic flops of one
-                     round / average launch duration, hipEvents on the library's stream around the rounds of every sweep
-                     of the timed region;
+    `roofline`       the DOMINANT kernel of the step - since round 3 the Householder tridiagonalisation of the T x T Gram
+                     matrix (trd_resident_kernel, csrc/tridiag.h; the block-Jacobi round kernel when XMCA_TRIDIAG=0):
+                     algorithmic flops / average launch duration, hipEvents on the library's stream in the timed region;
     `roofline_gemm`  the covariance (Gram) GEMM, the kernel north_star quotes an MFMA utilisation for;
+    `roofline_c5`    the same product at BASELINE configs[4] (T = 1200 x N = 1 036 800 float32, resident field);
     `cpu_baseline`   the numpy oracle on this host (N = 1 only): one C2 solve()+rotate() and one reduced C4 surrogate.
 """
 import argparse
@@ -56,22 +57,45 @@ def device_step(h, T, N, n_rot, power, dtype):
     return sig, out
 
 
+def csrc_hash():
+    """sha256 (16 hex digits) over the kernel sources: the PMC file below is only valid for the build it was taken from."""
+    import hashlib
+    hh = hashlib.sha256()
+    base = os.path.join(REPO, "xmca_amd", "csrc")
+    for name in sorted(os.listdir(base)):
+        with open(os.path.join(base, name), "rb") as f:
+            hh.update(name.encode() + b"\0" + f.read())
+    return hh.hexdigest()[:16]
+
+
+PMC_FILE = os.path.join("profiles", "r03_pmc_c2.json")
+
+
 def pmc_traffic(kernel, same_workload):
-    """HBM-side bytes per launch of `kernel` from the committed PMC passes (profiles/r02_pmc_c2.json: separate rocprofv3 --pmc
-    runs of `bench.py --steps 1` at the default workload, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950);
-    None when the file is absent or the workload is not the one that was profiled."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_c2.json")
+    """HBM-side bytes per launch of `kernel` from the committed PMC passes (profiles/r03_pmc_c2.json: separate rocprofv3 --pmc
+    runs of `bench.py --steps 1` at the default workload, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
+    The file carries the hash of xmca_amd/csrc it was measured on: None (never a stale number) when the sources have
+    changed since, when the file is absent or when the workload is not the one that was profiled."""
+    path = os.path.join(REPO, PMC_FILE)
     if not same_workload or not os.path.exists(path):
         return None
     try:
         with open(path) as f:
-            return float(json.load(f)[kernel]["hbm_side_bytes_per_launch_gfx950_corrected"])
+            d = json.load(f)
+        if d.get("csrc_sha16") != csrc_hash():
+            return None
+        return float(d[kernel]["hbm_side_bytes_per_launch_gfx950_corrected"])
     except (KeyError, ValueError, OSError):
         return None
 
 
 def launch_ranks(args):
     """--gpus N > 1 outside a launcher: re-run this script as N ranks (one per GPU) and pass rank 0's line through."""
+    if os.environ.get("XMCA_BENCH_SHARE_GPU") != "1":
+        import torch
+        if torch.cuda.device_count() < args.gpus:
+            sys.exit("bench.py: --gpus %d but only %d GPU(s) visible (XMCA_BENCH_SHARE_GPU=1 puts every rank on GPU 0)"
+                     % (args.gpus, torch.cuda.device_count()))
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -108,9 +132,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rule-n", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
-    ap.add_argument("--rule-n-runs", type=int, default=4, help="timed rule_n surrogates per GPU (C4 configuration)")
-    ap.add_argument("--rule-n-rotated", action="store_true",
-                    help="also time the ROTATED C4 variant (n_rot=20, power=4) and report its dropped runs")
+    ap.add_argument("--rule-n-runs", type=int, default=25,
+                    help="timed rule_n surrogates per GPU (C4 configuration; BASELINE configs[3]: 25 runs per GPU)")
+    ap.add_argument("--rule-n-rotated-runs", type=int, default=4,
+                    help="runs per GPU of the ROTATED C4 variant (n_rot=20, power=4) with its dropped-run count; 0 = skip")
+    ap.add_argument("--no-c5", action="store_true", help="skip the C5 covariance-GEMM roofline leg (5 GB float32 field)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -166,6 +192,9 @@ def main():
     timings = h.timings()
     round_ms = timings.pop("jacobi_round_kernel_ms", 0.0)
     round_launches = timings.pop("jacobi_round_kernel_launches", 0.0)
+    trd_ms = timings.pop("trd_reduce_kernel_ms", 0.0)
+    trd_calls = timings.pop("trd_reduce_calls", 0.0)
+    trd_resident = timings.pop("trd_resident_calls", 0.0)
     stages = {k: v / args.steps for k, v in timings.items()}
     stages["eigh_info"] = h.solve_info()[0]
     if td is not None:
@@ -191,14 +220,38 @@ def main():
         roofline = {"kernel": "jacobi_fused_round_kernel<%d,real> (v_mfma_f64_16x16x4_f64; one launch per round, %d rounds per sweep)"
                               % (nt, 2 * S - 1),
                     "bound": "mfma", "achieved": tf, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / F64_MFMA_PEAK_TF,
-                    "traffic": pmc_traffic("jacobi_fused_round_kernel<64,false>", (T, N) == (2920, 10000) and nt == 64),
-                    "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at the default workload, "
-                                      "gfx950-corrected, bytes per launch: profiles/r02_pmc_c2.json (scripts/r02_profiles.sh); "
-                                      "null for any other workload",
+                    "traffic": None,
+                    "traffic_source": "profiles/r02_pmc_c2.json holds the round-2 PMC passes of this kernel (240.6 MB per launch); not "
+                                      "re-measured for this build, hence null",
                     "flops_per_launch": flops_round, "avg_launch_us": us_round, "launches_per_step": round_launches / args.steps,
                     "share_of_step": round_ms / args.steps / ms_per_step,
                     "algorithmic_bytes": bytes_round, "algorithmic_GBs": bytes_round / us_round / 1e3,
                     "frac_of_hbm_peak": bytes_round / us_round / 1e3 / 8000.0}
+
+    # ---- ... or, on the tridiagonal route (csrc/tridiag.h, the default since round 3), the Householder reduction of the T x T
+    # Gram matrix: per column j the trailing (T-j)^2 block gets its rank-2 update (2 FMA per element) and is multiplied by
+    # the reflector (1 FMA): 6 (T-j)^2 flop, 2 T^3 in total - float64 VECTOR FMAs (78.6 TF, the same figure as the f64 matrix
+    # peak on MI355X; the kernel has no MFMA).  It is neither flop- nor HBM-bound: the matrix lives in registers and every
+    # column costs one all-to-all exchange between the 256 workgroups (`exchange_us_per_column`).
+    if trd_calls > 0 and trd_ms / args.steps > (round_ms / args.steps if round_launches else 0.0):
+        flops_trd = 2.0 * float(T) ** 3
+        ms_trd = trd_ms / trd_calls
+        tf = flops_trd / ms_trd / 1e9
+        resident = trd_resident >= trd_calls
+        roofline = {"kernel": ("trd_resident_kernel<real,NC=%d,RR=4> (Householder tridiagonalisation of the T x T Gram matrix, ONE "
+                               "persistent launch, matrix resident in registers, one grid exchange per column)" % (8 * -(-T // 1024))
+                               if resident else "trd_step_kernel (Householder tridiagonalisation, one launch per column)"),
+                    "bound": "mfma", "achieved": tf, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / F64_MFMA_PEAK_TF,
+                    "note": "float64 vector FMAs (vector peak = matrix peak = 78.6 TF on MI355X); latency-bound by design: T "
+                            "dependent columns, each one exchange across the chip",
+                    "traffic": pmc_traffic("trd_resident_kernel", (T, N) == (2920, 10000) and resident),
+                    "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at the default workload, "
+                                      "gfx950-corrected, bytes per launch: %s (scripts/r03_profiles.sh), stamped with the hash "
+                                      "of xmca_amd/csrc; null when the sources differ or for any other workload" % PMC_FILE,
+                    "flops_per_launch": flops_trd, "avg_launch_ms": ms_trd, "launches_per_step": trd_calls / args.steps,
+                    "share_of_step": trd_ms / args.steps / ms_per_step, "exchange_us_per_column": 1e3 * ms_trd / T,
+                    "algorithmic_bytes": 8.0 * T * T if resident else 16.0 * T ** 3 / 3.0,
+                    "algorithmic_GBs": (8.0 * T * T if resident else 16.0 * T ** 3 / 3.0) / ms_trd / 1e6}
 
     # ---- the covariance (Gram) GEMM, measured live with hipEvents on the library's stream ----
     g = h.bench_gram(0, 5)
@@ -262,24 +315,50 @@ def main():
             tt = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
             td.all_reduce(tt, op=td.ReduceOp.MAX)
             dt = float(tt.item())
+        lanes = int(os.environ.get("XMCA_RULE_N_LANES", "2"))
         extra["rule_n"] = {"config": "C4: MCA T=%d x (%d, %d) f64 surrogates, complexify=True, unrotated; %d runs per GPU, "
-                                     "run-sharded, one all_gather (%s); two surrogates in flight per GPU (XMCA_RULE_N_LANES)" % (
-                                         Tn, Nxn, Nyn, args.rule_n_runs, backend if world > 1 else "single rank"),
-                           "runs": n_runs, "surrogates_per_s": n_runs / dt, "shape": list(sp.shape),
+                                     "run-sharded, one all_gather (%s); %d surrogates in flight per GPU (XMCA_RULE_N_LANES)" % (
+                                         Tn, Nxn, Nyn, args.rule_n_runs, backend if world > 1 else "single rank", lanes),
+                           "runs": n_runs, "runs_per_gpu": args.rule_n_runs, "lanes_per_gpu": lanes, "seconds": dt,
+                           "surrogates_per_s": n_runs / dt, "shape": list(sp.shape),
                            "spectrum_sum_check": float(abs(sp.sum(axis=0) / model._get_variance().sum() - 1).max())}
-        if args.rule_n_rotated:
+        if args.rule_n_rotated_runs > 0:
+            n_rot_runs = args.rule_n_rotated_runs * world
             model._analysis.update({'is_rotated': True, 'n_rot': 20, 'power': 4})
             model._norm = {'left': np.ones(20), 'right': np.ones(20)}
             model._var_idx = np.arange(20)
             barrier()
             t0 = time.perf_counter()
-            spr = model.rule_n(n_runs, seed=1)
+            spr = model.rule_n(n_rot_runs, seed=1)
             barrier()
             dtr = time.perf_counter() - t0
             extra["rule_n_rotated"] = {"config": "C4 rotated: n_rot=20, power=4 (complex white noise: Varimax rarely converges in "
                                                  "1000 iterations; the reference drops those runs, array.py:1759-1763)",
-                                       "runs": n_runs, "kept": int(spr.shape[1]), "dropped": int(n_runs - spr.shape[1]),
-                                       "surrogates_per_s": n_runs / dtr}
+                                       "runs": n_rot_runs, "kept": int(spr.shape[1]), "dropped": int(n_rot_runs - spr.shape[1]),
+                                       "surrogates_per_s": n_rot_runs / dtr}
+
+    # ---- BASELINE configs[4]: the covariance GEMM at the large-grid size, T = 1200 x N = 1 036 800 float32 (4.98 GB resident) --
+    # The Gram matrix X X^T of the dual formulation (xmca/array.py:479 on the float32 field), T (T + 1) N useful flops (upper
+    # block triangle), f32 MFMA with float64 side accumulation.  hipEvents on the library's stream; 3 products.
+    if rank == 0 and world == 1 and not args.no_c5:
+        try:
+            T5, N5 = 1200, 1_036_800
+            rng5 = np.random.default_rng(5)
+            X5 = rng5.standard_normal((T5, N5), dtype=np.float32)
+            h5 = _hip.Handle(local_rank)
+            h5.set_field(0, X5)
+            del X5
+            h5.bench_gram(0, 1)
+            g5 = h5.bench_gram(0, 3)
+            tf5 = g5["flops"] / (g5["kernel_ms"] * 1e-3) / 1e12
+            extra["roofline_c5"] = {"kernel": "gemm_nt_kernel<f32> (Gram X X^T of the resident T=1200 x N=1036800 float32 field, "
+                                              "v_mfma_f32, float64 side accumulators, stream-K)", "bound": "mfma",
+                                    "achieved": tf5, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf5 / F32_MFMA_PEAK_TF,
+                                    "traffic": None, "flops_per_launch": g5["flops"], "avg_launch_ms": g5["kernel_ms"],
+                                    "product_ms_incl_reduction": g5["avg_ms"], "algorithmic_bytes": 4.0 * T5 * N5 + 8.0 * T5 * T5}
+            del h5
+        except Exception as e:                                    # noqa: BLE001  (reported, never fatal for the headline)
+            extra["roofline_c5"] = {"error": repr(e)[:300]}
 
     # ---- CPU baseline: the numpy oracle (formula-identical to the reference) on this host, N = 1 only ----
     cpu = None

@@ -252,7 +252,7 @@ def test_bench_py_launches_its_own_ranks():
     env = dict(os.environ, XMCA_BENCH_SHARE_GPU="1")
     env.pop("WORLD_SIZE", None)
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--T", "400",
-                        "--N", "1500", "--no-cpu-baseline", "--no-e2e", "--rule-n-runs", "1"], env=env, cwd=REPO,
+                        "--N", "1500", "--no-cpu-baseline", "--no-e2e", "--rule-n-runs", "1", "--rule-n-rotated-runs", "0"], env=env, cwd=REPO,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

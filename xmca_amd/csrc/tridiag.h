@@ -753,7 +753,7 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
           ok &= __hip_atomic_load(S.flags + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned int)(j + 1);
         if (__all(ok)) break;
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1u << 21)) { if (lane == 0) give_up_sh = 1; break; }     // a workgroup is missing: report, never hang
+        if (++spins > (1u << 17)) { if (lane == 0) give_up_sh = 1; break; }     // (~0.2 s) a workgroup is missing: report, never hang
       }
     }
     __syncthreads();
@@ -897,6 +897,24 @@ struct TrdWorkspace {
   DevBuf<double> sync;               // exchange buffers of the resident kernel
   DevBuf<unsigned int> flags;
   int resident_used = 0;             // 1: the last reduction ran as the persistent resident kernel, 2: it gave up and was repeated
+  // hipEvents around the reduction kernel(s) of every call (the dominant kernel of a solve: bench.py `roofline`)
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  bool ev_pending = false;
+  double reduce_ms = 0.0;
+  long long reduce_calls = 0;
+  long long resident_calls = 0;       // ... of which by the persistent resident kernel
+  void ev_begin(hipStream_t st) {
+    if (!ev[0]) { XMCA_HIP(hipEventCreate(&ev[0])); XMCA_HIP(hipEventCreate(&ev[1])); }
+    XMCA_HIP(hipEventRecord(ev[0], st));
+  }
+  void ev_end(hipStream_t st) { XMCA_HIP(hipEventRecord(ev[1], st)); ev_pending = true; }
+  void ev_collect() {      // after the stream has been synchronised
+    if (!ev_pending) return;
+    float t = 0.f;
+    if (hipEventSynchronize(ev[1]) == hipSuccess && hipEventElapsedTime(&t, ev[0], ev[1]) == hipSuccess) { reduce_ms += t; ++reduce_calls; }
+    ev_pending = false;
+  }
+  ~TrdWorkspace() { if (ev[0]) { (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]); } }
   double ms = 0.0;            // (profiling: accumulated device time of the reduction, when measured)
 };
 
@@ -1021,7 +1039,9 @@ inline TrdParams trd_reduce(hipStream_t st, TrdWorkspace& ws, const double* Ar, 
       // one persistent grid at a time per process: two of them (two surrogate lanes) could each hold a part of the CUs
       // and wait for the rest forever (bounded here, but slow)
       std::lock_guard<std::mutex> lock(trd_resident_mutex());
+      ws.ev_begin(st);
       hipLaunchKernelGGL(fn, dim3(wgs), dim3(TRD_RES_THREADS), lds, st, P, S, first_res);
+      ws.ev_end(st);
       XMCA_HIP(hipGetLastError());
       XMCA_HIP(hipMemcpyAsync(&gave_up, S.give_up, sizeof(int), hipMemcpyDeviceToHost, st));
       XMCA_HIP(hipStreamSynchronize(st));
@@ -1040,8 +1060,11 @@ inline TrdParams trd_reduce(hipStream_t st, TrdWorkspace& ws, const double* Ar, 
     }
     if (!gave_up) {
       ws.resident_used = 1;
+      ++ws.resident_calls;
+      ws.ev_collect();
       return P;
     }
+    ws.ev_pending = false;
     // a workgroup never became resident (another process holds CUs?): start again with one launch per column
     ws.resident_used = 2;
     hipLaunchKernelGGL(trd_copy_kernel, dim3(n), dim3(256), 0, st, Ar, Ai, n, lda, P.Ar, P.Ai, ld, ws.scal.get());
@@ -1067,12 +1090,14 @@ inline TrdParams trd_reduce(hipStream_t st, TrdWorkspace& ws, const double* Ar, 
     XMCA_HIP(hipMemsetAsync(P.prof, 0, sizeof(unsigned long long) * 8 * (size_t)n, st));
   }
   int wgs_prev = 1;
+  ws.ev_begin(st);
   for (int j = 0; j < n; ++j) {
     const int m = n - j - 1;
     const int wgs = std::max(1, std::min(TRD_MAX_WGS, (m + TRD_ROWS - 1) / TRD_ROWS));
     hipLaunchKernelGGL(fn, dim3(wgs), dim3(TRD_THREADS), lds, st, P, j, wgs_prev);
     wgs_prev = wgs;
   }
+  ws.ev_end(st);
   XMCA_HIP(hipGetLastError());
   if (prof_file) {
     std::vector<unsigned long long> hp((size_t)8 * n);
@@ -1105,6 +1130,7 @@ inline void trd_eigenvalues(hipStream_t st, TrdWorkspace& ws, const TrdParams& P
   XMCA_HIP(hipMemcpyAsync(&flag, ws.flag.get(), sizeof(int), hipMemcpyDeviceToHost, st));
   XMCA_HIP(hipMemcpyAsync(scal, ws.scal.get(), sizeof(double) * 2, hipMemcpyDeviceToHost, st));
   XMCA_HIP(hipStreamSynchronize(st));
+  ws.ev_collect();
   XMCA_CHECK(flag == 0 && scal[1] == 0.0, XMCA_ERR_NUMERIC, "SVD failed. NaN entries may be the problem.");
 }
 

@@ -560,6 +560,9 @@ void run_lanes(xmca_handle* h, int lanes, F&& lane_body) {
     h->ews.w32.round_ms += lane->ews.w32.round_ms; h->ews.w32.round_launches += lane->ews.w32.round_launches;
     lane->ews.w64.round_ms = lane->ews.w32.round_ms = 0.0;
     lane->ews.w64.round_launches = lane->ews.w32.round_launches = 0;
+    h->ews.trd.reduce_ms += lane->ews.trd.reduce_ms; h->ews.trd.reduce_calls += lane->ews.trd.reduce_calls;
+    h->ews.trd.resident_calls += lane->ews.trd.resident_calls;
+    lane->ews.trd.reduce_ms = 0.0; lane->ews.trd.reduce_calls = 0; lane->ews.trd.resident_calls = 0;
   }
   // memory parked in the lane pools is of no use to anybody until the next rule_n / bootstrap call: give large amounts back
   // (every lane stream has been synchronised above)
@@ -1006,6 +1009,12 @@ int xmca_get_timings(xmca_handle* h, char* names, int names_len, double* ms, int
     if (ms) { ms[n] = rk_ms; ms[n + 1] = rk_n; }
     n += 2;
   }
+  // ... and of the tridiagonal reduction (tridiag.h): total duration of the reduction kernel(s) and number of reductions
+  if (h->ews.trd.reduce_calls > 0 && n + 3 <= max_n) {
+    joined += (n ? ";" : "") + std::string("trd_reduce_kernel_ms;trd_reduce_calls;trd_resident_calls");
+    if (ms) { ms[n] = h->ews.trd.reduce_ms; ms[n + 1] = (double)h->ews.trd.reduce_calls; ms[n + 2] = (double)h->ews.trd.resident_calls; }
+    n += 3;
+  }
   if (names && names_len > 0) {
     std::strncpy(names, joined.c_str(), (size_t)names_len - 1);
     names[names_len - 1] = 0;
@@ -1018,6 +1027,9 @@ int xmca_reset_timings(xmca_handle* h) {
   try { h->tm.reset(); } catch (...) { return XMCA_ERR_HIP; }
   h->ews.w64.round_ms = h->ews.w32.round_ms = 0.0;
   h->ews.w64.round_launches = h->ews.w32.round_launches = 0;
+  h->ews.trd.reduce_ms = 0.0;
+  h->ews.trd.reduce_calls = 0;
+  h->ews.trd.resident_calls = 0;
   return XMCA_OK;
 }
 
