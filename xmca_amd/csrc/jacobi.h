@@ -161,11 +161,13 @@ inline void hermitian_evd_f32(hipStream_t st, EvdWorkspace& ws, const double* Ar
 // gaps, so 6 double sweeps follow 10 float ones (87 ms) instead of 12 double sweeps (73 ms).
 inline void hermitian_evd(hipStream_t st, EvdWorkspace& ws, const double* Ar, const double* Ai, int n, int64_t lda,
                           std::vector<double>& lam_host, double* lam_dev, double* Zr, double* Zi, int64_t ldz,
-                          EvdInfo* info = nullptr, int force_tile = 0) {
+                          EvdInfo* info = nullptr, int force_tile = 0, bool nearly_diagonal = false) {
+  // `nearly_diagonal`: the caller knows that a few Jacobi sweeps finish the problem (the weak block of solver.h, three
+  // sweeps) - cheaper than any reduction, whose cost does not depend on the matrix.
   // eigenvalues only (rule_n without rotation, every n_vec = 0 solve): Householder tridiagonalisation + Sturm multisection
   // (tridiag.h) - (4/3) n^3 flop in n launches instead of ~11 sweeps of 4 n^3.  XMCA_TRIDIAG=0 keeps the Jacobi sweeps.
   const int trd_min_n = [] { const char* e = std::getenv("XMCA_TRIDIAG_MIN_N"); return e ? std::atoi(e) : 192; }();
-  if (!Zr && trd_enabled() && n >= trd_min_n && trd_fits(n, Ai != nullptr)) {
+  if (!Zr && !nearly_diagonal && trd_enabled() && n >= trd_min_n && trd_fits(n, Ai != nullptr)) {
     TrdParams P = trd_reduce(st, ws.trd, Ar, Ai, n, lda, false);
     trd_eigenvalues(st, ws.trd, P, lam_host, lam_dev, ws.lam_tmp);
     if (info) {
@@ -178,7 +180,7 @@ inline void hermitian_evd(hipStream_t st, EvdWorkspace& ws, const double* Ar, co
   // blocked reflectors and a Newton-Schulz clean-up (tridiag_vec.h).  Spectra with clusters the clean-up cannot repair
   // (repeated eigenvalues, null spaces of dimension > 1) come back here and take the Jacobi sweeps below.
   const int trd_vec_min_n = [] { const char* e = std::getenv("XMCA_TRIDIAG_VEC_MIN_N"); return e ? std::atoi(e) : 768; }();
-  if (Zr && trd_enabled() && n >= trd_vec_min_n && trd_fits(n, Ai != nullptr)) {
+  if (Zr && !nearly_diagonal && trd_enabled() && n >= trd_vec_min_n && trd_fits(n, Ai != nullptr)) {
     TrdParams P = trd_reduce(st, ws.trd, Ar, Ai, n, lda, true);
     std::vector<double> lam_t;
     trd_eigenvalues(st, ws.trd, P, lam_t, lam_dev, ws.lam_tmp, ws.trdv.lam_asc.ensure((size_t)n));

@@ -70,9 +70,52 @@ __device__ __forceinline__ double trd_block_sum(double x, double* red) {
 // NS: LDS slots per thread (the vectors have at most NS * TRD_THREADS slots); PF: 128-column chunks of a wave's first row
 // requested before the prologue starts.
 constexpr int TRD_PF = 4;
+// wave sum with DPP row operations (no LDS crossbar): pairs, quads, half rows, rows, then the four row sums in a fixed order
+template <int CTRL>
+__device__ __forceinline__ double trd_dpp_f64(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double trd_wave_sum_dpp(double x) {
+  x += trd_dpp_f64<0xB1>(x);     // quad_perm [1,0,3,2]
+  x += trd_dpp_f64<0x4E>(x);     // quad_perm [2,3,0,1]
+  x += trd_dpp_f64<0x141>(x);    // row_half_mirror
+  x += trd_dpp_f64<0x140>(x);    // row_mirror: every lane of a 16-lane row holds the row sum
+  const int lo = __double2loint(x), hi = __double2hiint(x);
+  const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+  const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+  const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+  const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+// 1 / b and sqrt(s) from the hardware seeds + Newton steps (the IEEE division / sqrt sequences of the compiler are
+// ~200-cycle dependent chains; these sit on the serial path of every column)
+__device__ __forceinline__ double trd_rcp(double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  r = fma(fma(-b, r, 1.0), r, r);
+  r = fma(fma(-b, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ double trd_div(double a, double b) {
+  const double r = trd_rcp(b);
+  const double q = a * r;
+  return fma(fma(-q, b, a), r, q);
+}
+__device__ __forceinline__ double trd_sqrt(double s) {
+  if (!(s > 0.0)) return s == 0.0 ? 0.0 : NAN;
+  double r = __builtin_amdgcn_rsq(s);
+  r = r * fma(-0.5 * s * r, r, 1.5);
+  r = r * fma(-0.5 * s * r, r, 1.5);
+  double g = s * r;
+  g = fma(0.5 * r, fma(-g, g, s), g);
+  return g;
+}
+
 template <int NWAVES>
 __device__ __forceinline__ double trd_block_sum_n(double x, double* red) {
-  x = trd_wave_sum(x);
+  x = trd_wave_sum_dpp(x);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
   __syncthreads();
@@ -394,16 +437,26 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
   __shared__ double dj_sh;
   __shared__ int give_up_sh;
   constexpr int LV = NC * 128;                     // slots per vector = padded matrix order
-  constexpr int NS = LV / TRD_RES_THREADS;             // slots per thread
-  static_assert(LV % TRD_RES_THREADS == 0, "NC must be even");
+  constexpr int NS = LV / TRD_RES_THREADS;         // slots per thread
+  constexpr int CG = 4;                            // chunks per group of the pass (one liveness branch per group)
+  static_assert(LV % TRD_RES_THREADS == 0 && NC % CG == 0, "NC must be a multiple of 4");
   const int n = P.n;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: row ownership tests become scalar branches)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nwg = (int)gridDim.x, NW = nwg * (TRD_RES_THREADS / 64), g = (int)blockIdx.x * (TRD_RES_THREADS / 64) + wave;
   double* bV[2] = {trd_lds, trd_lds + 3 * LV};                       // v_{j-1}   (re, im)
   double* bW[2] = {trd_lds + LV, trd_lds + 4 * LV};                  // w_{j-1}
   double* bX[2] = {trd_lds + 2 * LV, trd_lds + 5 * LV};              // column j -> v_j
-  // ---- resident rows -> registers ----
+  // every pointer of the exchange in registers once (indexing the kernel arguments with the parity costs a scalar load
+  // and a wait per access)
+  double* const pub_r[2] = {S.pub[0][0], S.pub[1][0]};
+  double* const pub_i[2] = {S.pub[0][1], S.pub[1][1]};
+  double* const gp_r[2] = {S.gpart[0][0], S.gpart[1][0]};
+  double* const gp_i[2] = {S.gpart[0][1], S.gpart[1][1]};
+  double* const rb_r[2] = {S.rowbuf[0][0], S.rowbuf[1][0]};
+  double* const rb_i[2] = {S.rowbuf[0][1], S.rowbuf[1][1]};
+  unsigned int* const flags = S.flags;
+  // ---- resident rows -> registers (rows beyond the matrix: zeros, they stay zero) ----
   double2 ar[RR][NC], ai[RR][NC];
 #pragma unroll
   for (int t = 0; t < RR; ++t) {
@@ -429,87 +482,76 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
   const bool prof = P.prof && blockIdx.x == 0 && tid == 0;
   for (int j = 0; j < n; ++j) {
     const int prev = (j + 1) & 1, cur = j & 1;
-    if (prof) P.prof[8 * j + 0] = __builtin_amdgcn_s_memtime();
     const int m = n - j - 1;
-    // ---- prologue: p_{j-1}, its partial sums, row j ----
+    if (prof) P.prof[8 * j + 0] = __builtin_amdgcn_s_memtime();
+    // ---- prologue: p_{j-1}, its partial sums, row j - every load requested at once, no predicates (the buffers are
+    // zero-filled before the launch and hold row 0 in rowbuf[0]: column 0 needs no special case) ----
+    const double* const prr = pub_r[prev];
+    const double* const pri = pub_i[prev];
+    const double* const rwr = rb_r[cur];
+    const double* const rwi = rb_i[cur];
     double gr = 0.0, gi = 0.0;
-    if (j > 0 && tid < nwg) {
-      gr = trd_ld_sc1(S.gpart[prev][0] + tid);
-      if (CPLX) gi = trd_ld_sc1(S.gpart[prev][1] + tid);
+    if (tid < nwg) {
+      gr = trd_ld_sc1(gp_r[prev] + tid);
+      if (CPLX) gi = trd_ld_sc1(gp_i[prev] + tid);
     }
-    // (everything of the prologue goes through LDS: the registers belong to the resident rows)
-    double ar_ = 0.0, ai_ = 0.0;
-    if (j > 0) {
-      gr = trd_block_sum_n<TRD_RES_THREADS / 64>(gr, red);
-      if (CPLX) gi = trd_block_sum_n<TRD_RES_THREADS / 64>(gi, red);
-      ar_ = -0.5 * (tpr * gr - tpi * gi);
-      ai_ = -0.5 * (tpr * gi + tpi * gr);
+    double lr_[NS], li_[NS], lp_[NS], lq_[NS];
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+      const int k = tid + t * TRD_RES_THREADS;
+      lr_[t] = trd_ld_sc1(rwr + k);
+      lp_[t] = trd_ld_sc1(prr + k);
+      li_[t] = 0.0;
+      lq_[t] = 0.0;
+      if (CPLX) {
+        li_[t] = trd_ld_sc1(rwi + k);
+        lq_[t] = trd_ld_sc1(pri + k);
+      }
     }
-    // (slots below column j are dead - nothing reads them any more - and are skipped by whole strides of the workgroup;
-    //  the loads of four slots are requested together: they are agent-scope loads the compiler does not move by itself)
-    constexpr int NB = 4;
+    gr = trd_block_sum_n<TRD_RES_THREADS / 64>(gr, red);
+    if (CPLX) gi = trd_block_sum_n<TRD_RES_THREADS / 64>(gi, red);
+    const double ar_ = -0.5 * (tpr * gr - tpi * gi);
+    const double ai_ = -0.5 * (tpr * gi + tpi * gr);
+    // w_{j-1} = p_{j-1} + alpha v_{j-1};  conj(row j) parked in bX.  Slots outside [j, n) are written as zeros: dead columns
+    // stay zero in all three vectors, so the pass may touch them.
 #pragma unroll
-    for (int tb = 0; tb < NS; tb += NB) {
-      if ((tb + NB) * TRD_RES_THREADS > j) {
-        double rr_[NB], ri_[NB], pr_[NB], pi_[NB];
-#pragma unroll
-        for (int u = 0; u < NB; ++u) {
-          const int k = tid + (tb + u) * TRD_RES_THREADS;
-          const bool in = tb + u < NS && k >= j && k < n;
-          rr_[u] = ri_[u] = pr_[u] = pi_[u] = 0.0;
-          if (in) {
-            if (j == 0) {
-              rr_[u] = P.Ar[k];
-              if (CPLX) ri_[u] = P.Ai[k];
-            } else {
-              rr_[u] = trd_ld_sc1(S.rowbuf[cur][0] + k);
-              pr_[u] = trd_ld_sc1(S.pub[prev][0] + k);
-              if (CPLX) {
-                ri_[u] = trd_ld_sc1(S.rowbuf[cur][1] + k);
-                pi_[u] = trd_ld_sc1(S.pub[prev][1] + k);
-              }
-            }
-          }
+    for (int t = 0; t < NS; ++t) {
+      const int k = tid + t * TRD_RES_THREADS;
+      const bool in = k >= j && k < n;
+      double wr = 0.0, wi = 0.0, xr = 0.0, xi = 0.0;
+      if (in) {
+        const double vr = bV[0][k];
+        xr = lr_[t];
+        if (CPLX) {
+          const double vi = bV[1][k];
+          wr = lp_[t] + ar_ * vr - ai_ * vi;
+          wi = lq_[t] + ar_ * vi + ai_ * vr;
+          xi = -li_[t];
+        } else {
+          wr = lp_[t] + ar_ * vr;
         }
-#pragma unroll
-        for (int u = 0; u < NB; ++u) {
-          const int k = tid + (tb + u) * TRD_RES_THREADS;
-          if (tb + u < NS) {
-            const bool in = k >= j && k < n;
-            double wr = 0.0, wi = 0.0;
-            if (in && j > 0) {
-              const double vr = bV[0][k];
-              if (CPLX) {
-                const double vi = bV[1][k];
-                wr = pr_[u] + ar_ * vr - ai_ * vi;
-                wi = pi_[u] + ar_ * vi + ai_ * vr;
-              } else {
-                wr = pr_[u] + ar_ * vr;
-              }
-            }
-            bW[0][k] = wr;
-            bX[0][k] = rr_[u];                       // conj(row j) for now
-            if (CPLX) {
-              bW[1][k] = wi;
-              bX[1][k] = -ri_[u];
-            }
-          }
-        }
+      }
+      bW[0][k] = wr;
+      bX[0][k] = xr;
+      if (CPLX) {
+        bW[1][k] = wi;
+        bX[1][k] = xi;
       }
     }
     __syncthreads();
-    const double wjr = bW[0][j], vjr = j > 0 ? bV[0][j] : 0.0;
-    const double wji = CPLX ? bW[1][j] : 0.0, vji = (CPLX && j > 0) ? bV[1][j] : 0.0;
+    if (prof) P.prof[8 * j + 1] = __builtin_amdgcn_s_memtime();
+    const double wjr = bW[0][j], vjr = bV[0][j];
+    const double wji = CPLX ? bW[1][j] : 0.0, vji = CPLX ? bV[1][j] : 0.0;
     double xn2 = 0.0;
 #pragma unroll
     for (int t = 0; t < NS; ++t) {
       const int k = tid + t * TRD_RES_THREADS;
-      if ((t + 1) * TRD_RES_THREADS <= j) continue;          // dead stride
+      if ((t + 1) * TRD_RES_THREADS <= j) continue;          // dead stride: zeros already
       double xr = 0.0, xi = 0.0;
       if (k >= j && k < n) {
-        const double vr = j > 0 ? bV[0][k] : 0.0, wr = bW[0][k];
+        const double vr = bV[0][k], wr = bW[0][k];
         if (CPLX) {
-          const double vi = j > 0 ? bV[1][k] : 0.0, wi = bW[1][k];
+          const double vi = bV[1][k], wi = bW[1][k];
           xr = bX[0][k] - (vr * wjr + vi * wji) - (wr * vjr + wi * vji);
           xi = bX[1][k] - (vi * wjr - vr * wji) - (wi * vjr - wr * vji);
         } else {
@@ -527,21 +569,22 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
       if (CPLX) bX[1][k] = xi;
     }
     xn2 = trd_block_sum_n<TRD_RES_THREADS / 64>(xn2, red);
+    if (prof) P.prof[8 * j + 2] = __builtin_amdgcn_s_memtime();
     if (m == 0) {
       if (blockIdx.x == 0 && tid == 0) P.d[j] = dj_sh;
       break;
     }
-    if (prof) P.prof[8 * j + 2] = __builtin_amdgcn_s_memtime();
     const double a0r = bX[0][j + 1], a0i = CPLX ? bX[1][j + 1] : 0.0;
     double beta, tr, ti = 0.0, scr = 0.0, sci = 0.0;
     if (xn2 == 0.0 && a0i == 0.0) {
       beta = a0r;
       tr = 0.0;
     } else {
-      beta = -copysign(sqrt(a0r * a0r + a0i * a0i + xn2), a0r);
-      tr = (beta - a0r) / beta;
-      ti = -a0i / beta;
-      const double dr = a0r - beta, di = a0i, dn = 1.0 / (dr * dr + di * di);
+      beta = -copysign(trd_sqrt(a0r * a0r + a0i * a0i + xn2), a0r);
+      const double rb = trd_rcp(beta);
+      tr = fma(fma(-(beta - a0r) * rb, beta, beta - a0r), rb, (beta - a0r) * rb);
+      ti = -a0i * rb;
+      const double dr = a0r - beta, di = a0i, dn = trd_rcp(dr * dr + di * di);
       scr = dr * dn;
       sci = -di * dn;
     }
@@ -580,25 +623,109 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
     if (prof) P.prof[8 * j + 3] = __builtin_amdgcn_s_memtime();
     // ---- pass: resident rows in registers, early rows streamed from global memory ----
     // No liveness tests per row: a dead row (i <= j) keeps being updated - nobody reads its p_i (consumers start at j+1),
-    // and v_j[i] = 0 keeps it out of p^H v.  Only rows beyond the matrix (i >= n) are skipped, wave-uniformly.
-    const int c0 = (j + 1) >> 7;                    // chunks below hold dead columns only
+    // and v_j[i] = 0 keeps it out of p^H v; rows beyond the matrix are zero and stay zero (their scalars are zero).  Dead
+    // columns are zero in all three vectors; whole groups of CG dead chunks are skipped with one scalar branch.
+    const int g0 = ((j + 1) >> 7) / CG;             // groups below hold dead columns only
+    const int c0 = (j + 1) >> 7;
     double gwr = 0.0, gwi = 0.0;
-    if (first_res + g < n) {
+    double* const pbr = pub_r[cur];
+    double* const pbi = pub_i[cur];
+    double* const nrr = rb_r[prev];
+    double* const nri = rb_i[prev];
+    // early rows (i < first_res, owner wave i mod NW): the same from global memory - first, so that their stores are on
+    // their way while the resident rows are processed (the drain before the flag waits for every store of the wave)
+    {
+      int i = g;
+      if (i < j + 1) i += ((j + 1 - i + NW - 1) / NW) * NW;
+      for (; i < first_res; i += NW) {
+        const double svr_ = bV[0][i], swr_ = bW[0][i];
+        const double svi_ = CPLX ? bV[1][i] : 0.0, swi_ = CPLX ? bW[1][i] : 0.0;
+        double* rowr = P.Ar + (int64_t)i * P.ld;
+        double* rowi = CPLX ? P.Ai + (int64_t)i * P.ld : nullptr;
+        double sr = 0.0, si = 0.0;
+        const bool pubrow = i == j + 1;
+        // four chunks per trip, their loads requested together (one wave streams a whole row: latency-bound otherwise)
+        for (int kb = 128 * c0; kb < LV; kb += 4 * 128) {
+          double2 la[4], lb[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int k = kb + 128 * u + 2 * lane;
+            la[u] = make_double2(0.0, 0.0);
+            lb[u] = make_double2(0.0, 0.0);
+            if (k < LV) {
+              la[u] = *reinterpret_cast<const double2*>(rowr + k);
+              if (CPLX) lb[u] = *reinterpret_cast<const double2*>(rowi + k);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int k = kb + 128 * u + 2 * lane;
+            if (k < LV) {
+              double2 a = la[u];
+              const double2 wk = *reinterpret_cast<const double2*>(bW[0] + k);
+              const double2 vk = *reinterpret_cast<const double2*>(bV[0] + k);
+              const double2 xk = *reinterpret_cast<const double2*>(bX[0] + k);
+              if (CPLX) {
+                double2 b = lb[u];
+                const double2 wki = *reinterpret_cast<const double2*>(bW[1] + k);
+                const double2 vki = *reinterpret_cast<const double2*>(bV[1] + k);
+                const double2 xki = *reinterpret_cast<const double2*>(bX[1] + k);
+                a.x -= (svr_ * wk.x + svi_ * wki.x) + (swr_ * vk.x + swi_ * vki.x);
+                b.x -= (svi_ * wk.x - svr_ * wki.x) + (swi_ * vk.x - swr_ * vki.x);
+                a.y -= (svr_ * wk.y + svi_ * wki.y) + (swr_ * vk.y + swi_ * vki.y);
+                b.y -= (svi_ * wk.y - svr_ * wki.y) + (swi_ * vk.y - swr_ * vki.y);
+                *reinterpret_cast<double2*>(rowr + k) = a;
+                *reinterpret_cast<double2*>(rowi + k) = b;
+                sr += a.x * xk.x - b.x * xki.x;
+                si += a.x * xki.x + b.x * xk.x;
+                sr += a.y * xk.y - b.y * xki.y;
+                si += a.y * xki.y + b.y * xk.y;
+                if (pubrow) {
+                  trd_st_sc1(nri + k, b.x);
+                  trd_st_sc1(nri + k + 1, b.y);
+                }
+              } else {
+                a.x -= svr_ * wk.x + swr_ * vk.x;
+                a.y -= svr_ * wk.y + swr_ * vk.y;
+                *reinterpret_cast<double2*>(rowr + k) = a;
+                sr += a.x * xk.x;
+                sr += a.y * xk.y;
+              }
+              if (pubrow) {
+                trd_st_sc1(nrr + k, a.x);
+                trd_st_sc1(nrr + k + 1, a.y);
+              }
+            }
+          }
+        }
+        const double yr = trd_wave_sum_dpp(sr);
+        const double yi = CPLX ? trd_wave_sum_dpp(si) : 0.0;
+        const double pr = tr * yr - ti * yi, pi = tr * yi + ti * yr;
+        const double vr = bX[0][i], vi = CPLX ? bX[1][i] : 0.0;
+        if (lane == 0) {
+          trd_st_sc1(pbr + i, pr);
+          if (CPLX) trd_st_sc1(pbi + i, pi);
+        }
+        gwr += pr * vr + pi * vi;
+        gwi += pr * vi - pi * vr;
+      }
+    }
+    if (first_res + g + NW * (RR - 1) > j) {        // (uniform) the wave still owns a live resident row
       double vpr[RR], vpi[RR], wpr[RR], wpi[RR], accr[RR], acci[RR];
-      bool any = false;
 #pragma unroll
       for (int t = 0; t < RR; ++t) {
         const int i = first_res + g + NW * t;
-        const int ii = i < n ? i : 0;
-        any |= i < n && i > j;
-        vpr[t] = bV[0][ii]; wpr[t] = bW[0][ii];
-        vpi[t] = CPLX ? bV[1][ii] : 0.0; wpi[t] = CPLX ? bW[1][ii] : 0.0;
+        const int ii = i < n ? i : 0;                // (bV[0] = bW[0] = 0 from column 1 on, and the registers of such a row are 0)
+        vpr[t] = i < n ? bV[0][ii] : 0.0; wpr[t] = i < n ? bW[0][ii] : 0.0;
+        vpi[t] = (CPLX && i < n) ? bV[1][ii] : 0.0; wpi[t] = (CPLX && i < n) ? bW[1][ii] : 0.0;
         accr[t] = 0.0; acci[t] = 0.0;
       }
-      if (any) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          if (c >= c0) {
+      for (int cg = 0; cg < NC / CG; ++cg) {
+        if (cg >= g0) {
+#pragma unroll
+          for (int cc = 0; cc < CG; ++cc) {
+            const int c = cg * CG + cc;
             const int k = 128 * c + 2 * lane;
             const double2 wk = *reinterpret_cast<const double2*>(bW[0] + k);
             const double2 vk = *reinterpret_cast<const double2*>(bV[0] + k);
@@ -611,120 +738,61 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
             }
 #pragma unroll
             for (int t = 0; t < RR; ++t) {
-              if (first_res + g + NW * t < n) {            // wave-uniform
-                double2 a = ar[t][c];
-                if (CPLX) {
-                  double2 b = ai[t][c];
-                  // a -= v'_i conj(w'_k) + w'_i conj(v'_k)
-                  a.x = fma(-vpr[t], wk.x, a.x);  a.x = fma(-vpi[t], wki.x, a.x);  a.x = fma(-wpr[t], vk.x, a.x);  a.x = fma(-wpi[t], vki.x, a.x);
-                  b.x = fma(-vpi[t], wk.x, b.x);  b.x = fma(vpr[t], wki.x, b.x);   b.x = fma(-wpi[t], vk.x, b.x);  b.x = fma(wpr[t], vki.x, b.x);
-                  a.y = fma(-vpr[t], wk.y, a.y);  a.y = fma(-vpi[t], wki.y, a.y);  a.y = fma(-wpr[t], vk.y, a.y);  a.y = fma(-wpi[t], vki.y, a.y);
-                  b.y = fma(-vpi[t], wk.y, b.y);  b.y = fma(vpr[t], wki.y, b.y);   b.y = fma(-wpi[t], vk.y, b.y);  b.y = fma(wpr[t], vki.y, b.y);
-                  ai[t][c] = b;
-                  accr[t] = fma(a.x, xk.x, accr[t]);  accr[t] = fma(-b.x, xki.x, accr[t]);
-                  acci[t] = fma(a.x, xki.x, acci[t]); acci[t] = fma(b.x, xk.x, acci[t]);
-                  accr[t] = fma(a.y, xk.y, accr[t]);  accr[t] = fma(-b.y, xki.y, accr[t]);
-                  acci[t] = fma(a.y, xki.y, acci[t]); acci[t] = fma(b.y, xk.y, acci[t]);
-                } else {
-                  a.x = fma(-vpr[t], wk.x, a.x);  a.x = fma(-wpr[t], vk.x, a.x);
-                  a.y = fma(-vpr[t], wk.y, a.y);  a.y = fma(-wpr[t], vk.y, a.y);
-                  accr[t] = fma(a.x, xk.x, accr[t]);
-                  accr[t] = fma(a.y, xk.y, accr[t]);
-                }
-                ar[t][c] = a;
+              double2 a = ar[t][c];
+              if (CPLX) {
+                double2 b = ai[t][c];
+                // a -= v'_i conj(w'_k) + w'_i conj(v'_k)
+                a.x = fma(-vpr[t], wk.x, a.x);  a.x = fma(-vpi[t], wki.x, a.x);  a.x = fma(-wpr[t], vk.x, a.x);  a.x = fma(-wpi[t], vki.x, a.x);
+                b.x = fma(-vpi[t], wk.x, b.x);  b.x = fma(vpr[t], wki.x, b.x);   b.x = fma(-wpi[t], vk.x, b.x);  b.x = fma(wpr[t], vki.x, b.x);
+                a.y = fma(-vpr[t], wk.y, a.y);  a.y = fma(-vpi[t], wki.y, a.y);  a.y = fma(-wpr[t], vk.y, a.y);  a.y = fma(-wpi[t], vki.y, a.y);
+                b.y = fma(-vpi[t], wk.y, b.y);  b.y = fma(vpr[t], wki.y, b.y);   b.y = fma(-wpi[t], vk.y, b.y);  b.y = fma(wpr[t], vki.y, b.y);
+                ai[t][c] = b;
+                accr[t] = fma(a.x, xk.x, accr[t]);  accr[t] = fma(-b.x, xki.x, accr[t]);
+                acci[t] = fma(a.x, xki.x, acci[t]); acci[t] = fma(b.x, xk.x, acci[t]);
+                accr[t] = fma(a.y, xk.y, accr[t]);  accr[t] = fma(-b.y, xki.y, accr[t]);
+                acci[t] = fma(a.y, xki.y, acci[t]); acci[t] = fma(b.y, xk.y, acci[t]);
+              } else {
+                a.x = fma(-vpr[t], wk.x, a.x);  a.x = fma(-wpr[t], vk.x, a.x);
+                a.y = fma(-vpr[t], wk.y, a.y);  a.y = fma(-wpr[t], vk.y, a.y);
+                accr[t] = fma(a.x, xk.x, accr[t]);
+                accr[t] = fma(a.y, xk.y, accr[t]);
               }
+              ar[t][c] = a;
             }
           }
-        }
-#pragma unroll
-        for (int t = 0; t < RR; ++t) {
-          const int i = first_res + g + NW * t;
-          if (i < n && i > j) {                            // wave-uniform
-            const double yr = trd_wave_sum(accr[t]);
-            const double yi = CPLX ? trd_wave_sum(acci[t]) : 0.0;
-            const double pr = tr * yr - ti * yi, pi = tr * yi + ti * yr;
-            const double vr = bX[0][i], vi = CPLX ? bX[1][i] : 0.0;
-            if (lane == 0) {
-              trd_st_sc1(S.pub[cur][0] + i, pr);
-              if (CPLX) trd_st_sc1(S.pub[cur][1] + i, pi);
-            }
-            gwr += pr * vr + pi * vi;
-            gwi += pr * vi - pi * vr;
-            if (i == j + 1) {                              // the next column's row: publish it as stored (update j applied next time)
-#pragma unroll
-              for (int c = 0; c < NC; ++c) {
-                if (c >= c0) {
-                  const int k = 128 * c + 2 * lane;
-                  trd_st_sc1(S.rowbuf[prev][0] + k, ar[t][c].x);
-                  trd_st_sc1(S.rowbuf[prev][0] + k + 1, ar[t][c].y);
-                  if (CPLX) {
-                    trd_st_sc1(S.rowbuf[prev][1] + k, ai[t][c].x);
-                    trd_st_sc1(S.rowbuf[prev][1] + k + 1, ai[t][c].y);
-                  }
-                }
-              }
-            }
-          }
+          // (keeps the LDS operands of later groups out of the registers of the resident rows)
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
-    }
-    // early rows (i < first_res, owner wave i mod NW): the same from global memory
-    {
-      int i = g;
-      if (i < j + 1) i += ((j + 1 - i + NW - 1) / NW) * NW;
-      for (; i < first_res; i += NW) {
-        const double svr_ = bV[0][i], swr_ = bW[0][i];
-        const double svi_ = CPLX ? bV[1][i] : 0.0, swi_ = CPLX ? bW[1][i] : 0.0;
-        double* rowr = P.Ar + (int64_t)i * P.ld;
-        double* rowi = CPLX ? P.Ai + (int64_t)i * P.ld : nullptr;
-        double sr = 0.0, si = 0.0;
-        const bool pubrow = i == j + 1;
-        for (int k = 128 * c0 + 2 * lane; k < LV; k += 128) {
-          double2 a = *reinterpret_cast<const double2*>(rowr + k);
-          const double2 wk = *reinterpret_cast<const double2*>(bW[0] + k);
-          const double2 vk = *reinterpret_cast<const double2*>(bV[0] + k);
-          const double2 xk = *reinterpret_cast<const double2*>(bX[0] + k);
-          if (CPLX) {
-            double2 b = *reinterpret_cast<const double2*>(rowi + k);
-            const double2 wki = *reinterpret_cast<const double2*>(bW[1] + k);
-            const double2 vki = *reinterpret_cast<const double2*>(bV[1] + k);
-            const double2 xki = *reinterpret_cast<const double2*>(bX[1] + k);
-            a.x -= (svr_ * wk.x + svi_ * wki.x) + (swr_ * vk.x + swi_ * vki.x);
-            b.x -= (svi_ * wk.x - svr_ * wki.x) + (swi_ * vk.x - swr_ * vki.x);
-            a.y -= (svr_ * wk.y + svi_ * wki.y) + (swr_ * vk.y + swi_ * vki.y);
-            b.y -= (svi_ * wk.y - svr_ * wki.y) + (swi_ * vk.y - swr_ * vki.y);
-            *reinterpret_cast<double2*>(rowr + k) = a;
-            *reinterpret_cast<double2*>(rowi + k) = b;
-            sr += a.x * xk.x - b.x * xki.x;
-            si += a.x * xki.x + b.x * xk.x;
-            sr += a.y * xk.y - b.y * xki.y;
-            si += a.y * xki.y + b.y * xk.y;
-            if (pubrow) {
-              trd_st_sc1(S.rowbuf[prev][1] + k, b.x);
-              trd_st_sc1(S.rowbuf[prev][1] + k + 1, b.y);
+#pragma unroll
+      for (int t = 0; t < RR; ++t) {
+        const int i = first_res + g + NW * t;
+        if (i < n && i > j) {                              // wave-uniform
+          const double yr = trd_wave_sum_dpp(accr[t]);
+          const double yi = CPLX ? trd_wave_sum_dpp(acci[t]) : 0.0;
+          const double pr = tr * yr - ti * yi, pi = tr * yi + ti * yr;
+          const double vr = bX[0][i], vi = CPLX ? bX[1][i] : 0.0;
+          if (lane == 0) {
+            trd_st_sc1(pbr + i, pr);
+            if (CPLX) trd_st_sc1(pbi + i, pi);
+          }
+          gwr += pr * vr + pi * vi;
+          gwi += pr * vi - pi * vr;
+          if (i == j + 1) {                              // the next column's row: publish it as stored (update j applied next time)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+              if (c >= c0) {
+                const int k = 128 * c + 2 * lane;
+                trd_st_sc1(nrr + k, ar[t][c].x);
+                trd_st_sc1(nrr + k + 1, ar[t][c].y);
+                if (CPLX) {
+                  trd_st_sc1(nri + k, ai[t][c].x);
+                  trd_st_sc1(nri + k + 1, ai[t][c].y);
+                }
+              }
             }
-          } else {
-            a.x -= svr_ * wk.x + swr_ * vk.x;
-            a.y -= svr_ * wk.y + swr_ * vk.y;
-            *reinterpret_cast<double2*>(rowr + k) = a;
-            sr += a.x * xk.x;
-            sr += a.y * xk.y;
-          }
-          if (pubrow) {
-            trd_st_sc1(S.rowbuf[prev][0] + k, a.x);
-            trd_st_sc1(S.rowbuf[prev][0] + k + 1, a.y);
           }
         }
-        const double yr = trd_wave_sum(sr);
-        const double yi = CPLX ? trd_wave_sum(si) : 0.0;
-        const double pr = tr * yr - ti * yi, pi = tr * yi + ti * yr;
-        const double vr = bX[0][i], vi = CPLX ? bX[1][i] : 0.0;
-        if (lane == 0) {
-          trd_st_sc1(S.pub[cur][0] + i, pr);
-          if (CPLX) trd_st_sc1(S.pub[cur][1] + i, pi);
-        }
-        gwr += pr * vr + pi * vi;
-        gwi += pr * vi - pi * vr;
       }
     }
     if (prof) P.prof[8 * j + 4] = __builtin_amdgcn_s_memtime();
@@ -737,12 +805,12 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
       double sr = 0.0, si = 0.0;
 #pragma unroll
       for (int w = 0; w < TRD_RES_THREADS / 64; ++w) { sr += gam_sh[w][0]; si += gam_sh[w][1]; }
-      trd_st_sc1(S.gpart[cur][0] + blockIdx.x, sr);
-      if (CPLX) trd_st_sc1(S.gpart[cur][1] + blockIdx.x, si);
+      trd_st_sc1(gp_r[cur] + blockIdx.x, sr);
+      if (CPLX) trd_st_sc1(gp_i[cur] + blockIdx.x, si);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every storing wave drains before the flag goes out
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(S.flags + blockIdx.x, (unsigned int)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(flags + blockIdx.x, (unsigned int)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (prof) P.prof[8 * j + 5] = __builtin_amdgcn_s_memtime();
     // ---- exchange: wait until every workgroup has published column j ----
     if (wave == 0) {
@@ -750,7 +818,7 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
       for (;;) {
         bool ok = true;
         for (int w = lane; w < nwg; w += 64)
-          ok &= __hip_atomic_load(S.flags + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned int)(j + 1);
+          ok &= __hip_atomic_load(flags + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned int)(j + 1);
         if (__all(ok)) break;
         __builtin_amdgcn_s_sleep(1);
         if (++spins > (1u << 17)) { if (lane == 0) give_up_sh = 1; break; }     // (~0.2 s) a workgroup is missing: report, never hang
@@ -1007,26 +1075,30 @@ inline TrdParams trd_reduce(hipStream_t st, TrdWorkspace& ws, const double* Ar, 
       if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
       return v > 0 ? v : 256;
     }();
-    const int rr = cplx ? 2 : 4;
+    const int rr = cplx ? (nc == 8 ? 1 : 2) : nc / 8;     // row slots per wave: all of the matrix (real), the last 2048 rows (complex)
     const int wgs = std::max(1, std::min(std::min(n_cus, TRD_MAX_WGS), ceil_div(n, (TRD_RES_THREADS / 64) * rr)));
     const int first_res = std::max(0, n - wgs * (TRD_RES_THREADS / 64) * rr);
     const size_t lv = (size_t)nc * 128;
-    const size_t sync_doubles = 4 * nv + 4 * (size_t)TRD_MAX_WGS + 4 * lv;
+    const size_t nvs = std::max(nv, lv);                   // (the prologue loads every slot of a vector, dead or not)
+    const size_t sync_doubles = 4 * nvs + 4 * (size_t)TRD_MAX_WGS + 4 * lv;
     ws.sync.ensure(sync_doubles);
     ws.flags.ensure(TRD_MAX_WGS + 4);
     XMCA_HIP(hipMemsetAsync(ws.sync.get(), 0, sizeof(double) * sync_doubles, st));
     XMCA_HIP(hipMemsetAsync(ws.flags.get(), 0, sizeof(unsigned int) * (TRD_MAX_WGS + 4), st));
     TrdSync S{};
     double* q = ws.sync.get();
-    for (int a = 0; a < 2; ++a) for (int c = 0; c < 2; ++c) { S.pub[a][c] = q; q += nv; }
+    for (int a = 0; a < 2; ++a) for (int c = 0; c < 2; ++c) { S.pub[a][c] = q; q += nvs; }
     for (int a = 0; a < 2; ++a) for (int c = 0; c < 2; ++c) { S.gpart[a][c] = q; q += TRD_MAX_WGS; }
     for (int a = 0; a < 2; ++a) for (int c = 0; c < 2; ++c) { S.rowbuf[a][c] = q; q += lv; }
     S.flags = ws.flags.get();
+    // column 0 reads its row like every other column: from rowbuf (parity 0)
+    XMCA_HIP(hipMemcpyAsync(S.rowbuf[0][0], P.Ar, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
+    if (cplx) XMCA_HIP(hipMemcpyAsync(S.rowbuf[0][1], P.Ai, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
     S.give_up = reinterpret_cast<int*>(ws.flags.get() + TRD_MAX_WGS);
     using ResFn = void (*)(TrdParams, TrdSync, int);
     ResFn fn = nullptr;
-    if (cplx) fn = nc == 8 ? trd_resident_kernel<true, 8, 2> : nc == 16 ? trd_resident_kernel<true, 16, 2> : trd_resident_kernel<true, 20, 2>;
-    else fn = nc == 8 ? trd_resident_kernel<false, 8, 4> : nc == 16 ? trd_resident_kernel<false, 16, 4> : trd_resident_kernel<false, 24, 4>;
+    if (cplx) fn = nc == 8 ? trd_resident_kernel<true, 8, 1> : nc == 16 ? trd_resident_kernel<true, 16, 2> : trd_resident_kernel<true, 20, 2>;
+    else fn = nc == 8 ? trd_resident_kernel<false, 8, 1> : nc == 16 ? trd_resident_kernel<false, 16, 2> : trd_resident_kernel<false, 24, 3>;
     const size_t lds = lv * 3 * (cplx ? 2 : 1) * sizeof(double);
     XMCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     static const char* prof_file_r = std::getenv("XMCA_TRD_PROF");
