@@ -86,7 +86,6 @@ struct EvdInfo {
   int slots = 0;
   double last_off = 0.0;
   int lr_step = 0;        // 1: a Cholesky LR step was inserted (graded spectrum)
-  int sweeps_f32 = 0;     // sweeps of the single-precision phase that preceded the `sweeps` double-precision ones
   double diag_spread = 0; // q10/q90 of the diagonal when that was decided
   int tridiag = 0;        // 1: solved by reduction to tridiagonal form (tridiag.h), no Jacobi sweeps
 };
@@ -108,20 +107,13 @@ using jreal = double;
 using jacc_t = d4_t;
 #include "jacobi_impl.inc"
 }  // namespace jac64
-namespace jac32 {
-using jreal = float;
-using jacc_t = f4_t;
-#include "jacobi_impl.inc"
-}  // namespace jac32
 
 struct EvdWorkspace {
   jac64::EvdWorkspaceT w64;
-  jac32::EvdWorkspaceT w32;
-  GemmWorkspace gws;             // products of the precision switch
+  GemmWorkspace gws;             // products of the tridiagonal route's back-transformation and clean-up
   TrdWorkspace trd;              // tridiagonal route (tridiag.h)
   TrdVecWorkspace trdv;          // ... its eigenvectors (tridiag_vec.h)
   DevBuf<double> lam_tmp;
-  DevBuf<double> mp[6];          // start basis, its Gram matrix, work planes
 };
 
 // one run in one precision; tile size by problem kind (64 x 64 complex tiles do not fit the LDS of the update kernel)
@@ -141,24 +133,14 @@ inline void hermitian_evd_f64(hipStream_t st, EvdWorkspace& ws, const double* Ar
                               const EvdParams& prm, EvdInfo* info, int force_tile) {
   XMCA_EVD_RUN(jac64, ws.w64);
 }
-inline void hermitian_evd_f32(hipStream_t st, EvdWorkspace& ws, const double* Ar, const double* Ai, int n, int64_t lda,
-                              std::vector<double>& lam_host, double* lam_dev, double* Zr, double* Zi, int64_t ldz,
-                              const EvdParams& prm, EvdInfo* info, int force_tile) {
-  XMCA_EVD_RUN(jac32, ws.w32);
-}
 #undef XMCA_EVD_RUN
 
 // Hermitian EVD  A = U diag(lam) U^H, lam descending (see jacobi_impl.inc for the arguments).
 //
-// Mixed precision is implemented but OFF by default (XMCA_JACOBI_MIXED=1 enables it for n >= 384 with eigenvectors,
-// =2 returns the single-precision result, for tests): sweeps on a float copy of the matrix (normalised to max |diag| = 1)
-// until they stall, their eigenvector basis Z1 orthonormalised in double (two Newton-Schulz steps
-// Z <- (3/2 I - 1/2 Z Z^H) Z), G2 = Z1 A Z1^H formed once, and double-precision sweeps from (G2, Z1) to the
-// double-precision stopping rule.  Correct (tests/test_gpu_kernels.py), but measured slower on MI355X at C2 (T = 2920):
-// a float round takes 40.7 us against 57.6 us in double - its update is bound by staging and store phases that do
-// not shrink with the element size (per eigenvector tile 7.7k vs 11.0k cycles, MFMA phase 3.7k vs 6.8k) - and the
-// matrix has 20 eigenvalues 1e5 above a dense bulk: the float basis leaves bulk-bulk couplings far above the bulk's
-// gaps, so 6 double sweeps follow 10 float ones (87 ms) instead of 12 double sweeps (73 ms).
+// Two solvers share this entry point: the reduction to tridiagonal form (tridiag.h, tridiag_vec.h: eigenproblems of 192 and
+// more without vectors, 768 and more with vectors) and the block Jacobi sweeps of this file (everything else, nearly
+// diagonal problems, and spectra with clusters the tridiagonal route hands back).  The mixed-precision variant of the
+// sweeps of rounds 1-2 (float sweeps, Newton-Schulz, double sweeps) was measured slower on MI355X and has been removed.
 inline void hermitian_evd(hipStream_t st, EvdWorkspace& ws, const double* Ar, const double* Ai, int n, int64_t lda,
                           std::vector<double>& lam_host, double* lam_dev, double* Zr, double* Zi, int64_t ldz,
                           EvdInfo* info = nullptr, int force_tile = 0, bool nearly_diagonal = false) {
@@ -202,56 +184,7 @@ inline void hermitian_evd(hipStream_t st, EvdWorkspace& ws, const double* Ar, co
   // push the vectors' first-order error down is not needed (C4 surrogates: 12 -> 11 sweeps)
   if (!Zr) prm.tol = 1e-8;
   if (const char* e = std::getenv("XMCA_JACOBI_TOL")) { if (std::atof(e) > 0.0) prm.tol = std::atof(e); }   // (experiments: scripts/eigh_tol_probe.py)
-  static const int mixed_mode = [] { const char* e = std::getenv("XMCA_JACOBI_MIXED"); return e ? std::atoi(e) : 0; }();   // 0 off, 1 on, 2 float only (tests)
-  if (mixed_mode == 0 || !Zr || n < 384) {
-    hermitian_evd_f64(st, ws, Ar, Ai, n, lda, lam_host, lam_dev, Zr, Zi, ldz, prm, info, force_tile);
-    return;
-  }
-  const bool cplx = Ai != nullptr;
-  const size_t nn = (size_t)n * n;
-  for (int k = 0; k < (cplx ? 6 : 5); k += (cplx ? 1 : 2)) ws.mp[k].ensure(nn);
-  double* z1r = ws.mp[0].get();
-  double* z1i = cplx ? ws.mp[1].get() : nullptr;
-  double* tr = ws.mp[2].get();
-  double* ti = cplx ? ws.mp[3].get() : nullptr;
-  double* br = ws.mp[4].get();
-  double* bi = cplx ? ws.mp[5].get() : nullptr;
-  EvdParams p32;
-  static const double f32_tol = [] { const char* e = std::getenv("XMCA_JACOBI_F32_TOL"); return e ? std::atof(e) : 1e-5; }();
-  static const double f32_stall = [] { const char* e = std::getenv("XMCA_JACOBI_F32_STALL"); return e ? std::atof(e) : 0.8; }();
-  static const int f32_max = [] { const char* e = std::getenv("XMCA_JACOBI_F32_MAX"); return e ? std::atoi(e) : 30; }();
-  p32.tol = f32_tol;       // relative to max |diag| of the float copy (normalised to 1)
-  p32.stall = f32_stall;
-  p32.max_sweeps = f32_max;
-  EvdInfo i32;
-  std::vector<double> lam32;
-  hermitian_evd_f32(st, ws, Ar, Ai, n, lda, lam32, nullptr, z1r, z1i, n, p32, &i32, force_tile);
-  if (mixed_mode == 2) {
-    lam_host = lam32;
-    if (lam_dev) XMCA_HIP(hipMemcpyAsync(lam_dev, lam_host.data(), sizeof(double) * n, hipMemcpyHostToDevice, st));
-    XMCA_HIP(hipMemcpy2DAsync(Zr, sizeof(double) * ldz, z1r, sizeof(double) * n, sizeof(double) * n, n, hipMemcpyDeviceToDevice, st));
-    if (cplx) XMCA_HIP(hipMemcpy2DAsync(Zi, sizeof(double) * ldz, z1i, sizeof(double) * n, sizeof(double) * n, n, hipMemcpyDeviceToDevice, st));
-    XMCA_HIP(hipStreamSynchronize(st));
-    if (info) *info = i32;
-    return;
-  }
-  // Z1 <- (3/2 I - 1/2 Z1 Z1^H) Z1, twice
-  for (int it = 0; it < 2; ++it) {
-    cgemm<double>(st, ws.gws, z1r, z1i, n, true, false, z1r, z1i, n, false, true, br, bi, n, n, n, n, 1.0, nullptr, nullptr, true);
-    XMCA_HIP(hipMemcpyAsync(tr, z1r, sizeof(double) * nn, hipMemcpyDeviceToDevice, st));
-    if (cplx) XMCA_HIP(hipMemcpyAsync(ti, z1i, sizeof(double) * nn, hipMemcpyDeviceToDevice, st));
-    cgemm<double>(st, ws.gws, br, bi, n, true, false, z1r, z1i, n, true, false, tr, ti, n, n, n, n, -0.5, nullptr, nullptr, false, 1.5);
-    std::swap(z1r, tr);
-    std::swap(z1i, ti);
-  }
-  // G2 = Z1 A Z1^H
-  cgemm<double>(st, ws.gws, z1r, z1i, n, true, false, Ar, Ai, lda, true, false, tr, ti, n, n, n, n, 1.0, nullptr, nullptr, false);
-  cgemm<double>(st, ws.gws, tr, ti, n, true, false, z1r, z1i, n, false, true, br, bi, n, n, n, n, 1.0, nullptr, nullptr, true);
-  prm.Z0r = z1r;
-  prm.Z0i = z1i;
-  prm.ldz0 = n;
-  hermitian_evd_f64(st, ws, br, bi, n, n, lam_host, lam_dev, Zr, Zi, ldz, prm, info, force_tile);
-  if (info) info->sweeps_f32 = i32.sweeps;
+  hermitian_evd_f64(st, ws, Ar, Ai, n, lda, lam_host, lam_dev, Zr, Zi, ldz, prm, info, force_tile);
 }
 
 }  // namespace xmca

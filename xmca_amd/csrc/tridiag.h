@@ -929,18 +929,34 @@ __global__ __launch_bounds__(TRD_BIS_THREADS) void trd_bisect_kernel(const doubl
   const int gshift = ((tid & 63) >> 4) * 16;
   for (int pass = 0; pass < 14; ++pass) {
     const double x = lo + (hi - lo) * ((double)(l + 1) * (1.0 / 17.0));
-    int cnt = 0;
-    double q = sd[0] - x;
-    if (fabs(q) < pivmin) q = -pivmin;
-    cnt += q < 0.0;
-#pragma unroll 4
-    for (int i = 1; i < n; ++i) {
-      double r = __builtin_amdgcn_rcp(q);
-      r = fma(fma(-q, r, 1.0), r, r);
-      r = fma(fma(-q, r, 1.0), r, r);
-      q = fma(-se2[i - 1], r, sd[i] - x);
-      if (fabs(q) < pivmin) q = -pivmin;
-      cnt += q < 0.0;
+    // Sturm count by the three-term recurrence of the leading principal minors, p_{i+1} = (d_i - x) p_i - e_{i-1}^2 p_{i-1}:
+    // count = sign changes along p_0 = 1, p_1, ..., p_n (a zero takes the sign opposite to its predecessor, the pivmin
+    // convention of dstebz).  One dependent FMA per row instead of a division; the pair (p_i, p_{i-1}) is rescaled by a
+    // power of two every eight rows (growth per row is bounded by ~5 for the scaled matrix, so neither overflows within
+    // eight rows, and the larger of the two is kept near 1).
+    double pm = 1.0, pc = sd[0] - x;
+    if (pc == 0.0) pc = -pivmin;
+    int cnt = pc < 0.0;
+    int i = 1;
+    for (; i + 8 <= n; i += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        double pn = fma(sd[i + u] - x, pc, -se2[i + u - 1] * pm);
+        if (pn == 0.0) pn = pc < 0.0 ? 4.9e-324 : -4.9e-324;
+        cnt += (pn < 0.0) != (pc < 0.0);
+        pm = pc;
+        pc = pn;
+      }
+      const int ex = __builtin_amdgcn_frexp_exp(fmax(fabs(pc), fabs(pm)));
+      pc = ldexp(pc, -ex);
+      pm = ldexp(pm, -ex);
+    }
+    for (; i < n; ++i) {
+      double pn = fma(sd[i] - x, pc, -se2[i - 1] * pm);
+      if (pn == 0.0) pn = pc < 0.0 ? 4.9e-324 : -4.9e-324;
+      cnt += (pn < 0.0) != (pc < 0.0);
+      pm = pc;
+      pc = pn;
     }
     const unsigned long long mask = __ballot(cnt <= k);
     const int s = __popcll((mask >> gshift) & 0xFFFFull);       // points at or below eigenvalue k (counts are monotone in x)

@@ -37,13 +37,13 @@ __global__ __launch_bounds__(64) void trd_twisted_kernel(const double* __restric
     if (!(fabs(dp) >= piv)) dp = dp < 0.0 ? -piv : piv;
     Yt[(int64_t)i * ldy + k] = dp;
     const double ei = e[i];
-    dp = (d[i + 1] - l) - (ei / dp) * ei;
+    dp = (d[i + 1] - l) - (ei * trd_rcp(dp)) * ei;
   }
   if (!(fabs(dp) >= piv)) dp = dp < 0.0 ? -piv : piv;
   Yt[(int64_t)(n - 1) * ldy + k] = dp;
   // backward: D- into W, gamma_i = D+_i + D-_i - (d_i - lambda), twist at the smallest |gamma|.  The loads of D+ do
-  // not depend on the recurrence: eight of them are requested at a time (the loops below are memory-latency bound).
-  constexpr int B = 16;
+  // not depend on the recurrence: 32 of them are requested at a time (the loops below are memory-latency bound).
+  constexpr int B = 32;
   double dm = d[n - 1] - l;
   int r = n - 1;
   double gbest = fabs(dp + dm - (d[n - 1] - l));
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(64) void trd_twisted_kernel(const double* __restric
       const int i = i0 - u;
       if (i >= 0) {
         const double ei = e[i];
-        dm = (d[i] - l) - (ei / dm) * ei;
+        dm = (d[i] - l) - (ei * trd_rcp(dm)) * ei;
         const double g = fabs(yp[u] + dm - (d[i] - l));
         if (g < gbest) { gbest = g; r = i; }
         if (!(fabs(dm) >= piv)) dm = dm < 0.0 ? -piv : piv;
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(64) void trd_twisted_kernel(const double* __restric
     for (int u = 0; u < B; ++u) {
       const int i = i0 - u;
       if (i >= 0) {
-        z = -(e[i] / yp[u]) * z;
+        z = -(e[i] * trd_rcp(yp[u])) * z;
         Yt[(int64_t)i * ldy + k] = z;
         nrm += z * z;
       }
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(64) void trd_twisted_kernel(const double* __restric
     for (int u = 0; u < B; ++u) {
       const int i = i0 + u;
       if (i < n - 1) {
-        z = -(e[i] / wm[u]) * z;
+        z = -(e[i] * trd_rcp(wm[u])) * z;
         Yt[(int64_t)(i + 1) * ldy + k] = z;
         nrm += z * z;
       }

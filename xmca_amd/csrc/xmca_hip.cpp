@@ -557,9 +557,8 @@ void run_lanes(xmca_handle* h, int lanes, F&& lane_body) {
     lane->tm.ms.clear();
     lane->tm.order.clear();
     h->ews.w64.round_ms += lane->ews.w64.round_ms; h->ews.w64.round_launches += lane->ews.w64.round_launches;
-    h->ews.w32.round_ms += lane->ews.w32.round_ms; h->ews.w32.round_launches += lane->ews.w32.round_launches;
-    lane->ews.w64.round_ms = lane->ews.w32.round_ms = 0.0;
-    lane->ews.w64.round_launches = lane->ews.w32.round_launches = 0;
+    lane->ews.w64.round_ms = 0.0;
+    lane->ews.w64.round_launches = 0;
     h->ews.trd.reduce_ms += lane->ews.trd.reduce_ms; h->ews.trd.reduce_calls += lane->ews.trd.reduce_calls;
     h->ews.trd.resident_calls += lane->ews.trd.resident_calls;
     lane->ews.trd.reduce_ms = 0.0; lane->ews.trd.reduce_calls = 0; lane->ews.trd.resident_calls = 0;
@@ -1002,8 +1001,8 @@ int xmca_get_timings(xmca_handle* h, char* names, int names_len, double* ms, int
   }
   // kernel-level entries: total duration and launch count of the eigensolver's fused round kernel (hipEvents around the
   // rounds of every sweep, jacobi_impl.inc) - ms[] carries the count for the second name
-  const double rk_ms = h->ews.w64.round_ms + h->ews.w32.round_ms;
-  const double rk_n = (double)(h->ews.w64.round_launches + h->ews.w32.round_launches);
+  const double rk_ms = h->ews.w64.round_ms;
+  const double rk_n = (double)h->ews.w64.round_launches;
   if (rk_n > 0 && n + 2 <= max_n) {
     joined += (n ? ";" : "") + std::string("jacobi_round_kernel_ms;jacobi_round_kernel_launches");
     if (ms) { ms[n] = rk_ms; ms[n + 1] = rk_n; }
@@ -1025,8 +1024,8 @@ int xmca_get_timings(xmca_handle* h, char* names, int names_len, double* ms, int
 int xmca_reset_timings(xmca_handle* h) {
   if (!h) return XMCA_ERR_INVALID;
   try { h->tm.reset(); } catch (...) { return XMCA_ERR_HIP; }
-  h->ews.w64.round_ms = h->ews.w32.round_ms = 0.0;
-  h->ews.w64.round_launches = h->ews.w32.round_launches = 0;
+  h->ews.w64.round_ms = 0.0;
+  h->ews.w64.round_launches = 0;
   h->ews.trd.reduce_ms = 0.0;
   h->ews.trd.reduce_calls = 0;
   h->ews.trd.resident_calls = 0;
