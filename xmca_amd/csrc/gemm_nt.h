@@ -51,15 +51,17 @@ struct GemmNtParams {
   int units_per_wg;
   double* partial;          // [grid][2][GEMM_BM * GEMM_BN] raw sums of partial segments
   int vec_a, vec_b;
+  int slabs;                // > 0: tile x K-slab schedule (one segment per workgroup, partial slot = slab * n_tiles + tile)
 };
 
-template <typename TI, typename TO, bool WIDE>
-__global__ __launch_bounds__(GEMM_THREADS, NtCfg<TI>::MINW) void gemm_nt_kernel(GemmNtParams<TI, TO> p) {
+// WGS: workgroups per CU the build is sized for (1: 256 registers per lane and two LDS buffers; 2: 128 registers, one buffer)
+template <typename TI, typename TO, bool WIDE, int WGS>
+__global__ __launch_bounds__(GEMM_THREADS, 2 * WGS) void gemm_nt_kernel(GemmNtParams<TI, TO> p) {
   using M_ = Mfma<TI>;
   using acc_t = typename M_::acc_t;
   using vec_t = typename M_::vec_t;
   using IO = GemmTileIO<TI, true>;
-  constexpr int PITCH = NtCfg<TI>::PITCH, NBUF = NtCfg<TI>::NBUF, VW = M_::VW, NV = 8 / VW;
+  constexpr int PITCH = NtCfg<TI>::PITCH, NBUF = 3 - WGS, VW = M_::VW, NV = 8 / VW;
   __shared__ __attribute__((aligned(16))) TI As[NBUF][GEMM_BM][PITCH];
   __shared__ __attribute__((aligned(16))) TI Bs[NBUF][GEMM_BN][PITCH];
 
@@ -85,8 +87,20 @@ __global__ __launch_bounds__(GEMM_THREADS, NtCfg<TI>::MINW) void gemm_nt_kernel(
     }
   };
 
-  long long u = (long long)L * p.units_per_wg;
-  const long long uend = u + p.units_per_wg < p.total_units ? u + p.units_per_wg : p.total_units;
+  // two schedules: stream-K (equal contiguous unit ranges) or, `slabs` > 0, tile x K-slab: workgroup b owns tile b % n_tiles
+  // over the slab b / n_tiles of the contraction - the workgroups of one slab walk through the same columns of the operands
+  // at the same time, so every panel is fetched from HBM once and re-read from L2 / Infinity Cache by the other tiles
+  long long u, uend;
+  if (p.slabs > 0) {
+    const int tile = (int)blockIdx.x % p.n_tiles, sl = (int)blockIdx.x / p.n_tiles;
+    L = sl * p.n_tiles + tile;
+    const int k0 = (int)((long long)sl * p.nkt / p.slabs), k1 = (int)((long long)(sl + 1) * p.nkt / p.slabs);
+    u = (long long)tile * p.nkt + k0;
+    uend = (long long)tile * p.nkt + k1;
+  } else {
+    u = (long long)L * p.units_per_wg;
+    uend = u + p.units_per_wg < p.total_units ? u + p.units_per_wg : p.total_units;
+  }
   int seg = 0;
   while (u < uend) {
     const int tile = (int)(u / p.nkt), kt0 = (int)(u - (long long)tile * p.nkt);
@@ -199,7 +213,7 @@ __global__ __launch_bounds__(GEMM_THREADS, NtCfg<TI>::MINW) void gemm_nt_kernel(
     } else {
       // raw partial sums of this segment: slot 0 = the first segment of this workgroup, slot 1 = a later one (only the
       // last segment of a range can be partial besides the first)
-      double* __restrict__ W = p.partial + ((size_t)L * 2 + (seg == 0 ? 0 : 1)) * (size_t)(GEMM_BM * GEMM_BN);
+      double* __restrict__ W = p.partial + (p.slabs > 0 ? (size_t)L : (size_t)L * 2 + (seg == 0 ? 0 : 1)) * (size_t)(GEMM_BM * GEMM_BN);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -250,6 +264,32 @@ __global__ __launch_bounds__(256) void gemm_nt_fixup_kernel(const double* __rest
   }
 }
 
+// tile x K-slab schedule: partial[slab][tile] summed over the slabs in order, then the epilogue
+template <typename TO>
+__global__ __launch_bounds__(256) void gemm_nt_slab_fixup_kernel(const double* __restrict__ partial, const int* __restrict__ tile_map,
+                                                                 int n_tiles, int slabs, TO* __restrict__ C, int M, int N, int64_t ldc,
+                                                                 double alpha, double beta, const double* __restrict__ row_scale,
+                                                                 const double* __restrict__ col_scale, int mirror) {
+  const int tile = blockIdx.x;
+  const int packed = tile_map[tile];
+  const int bm = packed >> 16, bn = packed & 0xffff;
+  constexpr int TE = GEMM_BM * GEMM_BN;
+  for (int e = threadIdx.x; e < TE; e += 256) {
+    double v = 0.0;
+    for (int sl = 0; sl < slabs; ++sl) v += partial[((size_t)sl * n_tiles + tile) * TE + e];
+    const int row = bm * GEMM_BM + e / GEMM_BN, col = bn * GEMM_BN + e % GEMM_BN;
+    if (row < M && col < N) {
+      v *= alpha;
+      if (row_scale) v *= row_scale[row];
+      if (col_scale) v *= col_scale[col];
+      const int64_t o = (int64_t)row * ldc + col;
+      if (beta != 0.0) v += beta * (double)C[o];
+      C[o] = (TO)v;
+      if (mirror != 0 && bm != bn) C[(int64_t)col * ldc + row] = (TO)(mirror > 0 ? v : -v);
+    }
+  }
+}
+
 // returns false when the problem should go to the general kernel instead (disabled / tiny)
 template <typename TI, typename TO>
 bool gemm_nt(hipStream_t st, GemmWorkspace& ws, GemmNtWorkspace& nws, const TI* A, int64_t lda, const TI* B, int64_t ldb, TO* C,
@@ -276,8 +316,31 @@ bool gemm_nt(hipStream_t st, GemmWorkspace& ws, GemmNtWorkspace& nws, const TI* 
   XMCA_CHECK(map.n == tiles && tm < 65536 && tn < 65536, XMCA_ERR_INVALID, "gemm: tile map mismatch");
   constexpr bool WIDE = std::is_same<TI, float>::value;
   constexpr int VW = Mfma<TI>::VW;
-  const int max_wgs = nws.n_cus * NtCfg<TI>::WGS_PER_CU;
   const long long total = (long long)tiles * nkt;
+  const int vec_a = (lda % VW == 0) && (reinterpret_cast<uintptr_t>(A) % 16 == 0);
+  const int vec_b = (ldb % VW == 0) && (reinterpret_cast<uintptr_t>(B) % 16 == 0);
+  // Few output tiles and a long contraction (the Gram matrix of a field with many more columns than rows: C5 has 55 upper
+  // tiles and 32 400 k-tiles): tile x K-slab schedule, one workgroup per CU with the 256-register build (no spills) and
+  // double-buffered LDS.  Stream-K gives every tile's K-range to neighbouring workgroups, which then share nothing: 58 GB of
+  // operand traffic at C5 for a 5 GB field; here the workgroups of a slab read the same panels at the same time.
+  static const bool slab_on = [] { const char* e = std::getenv("XMCA_NT_SLABS"); return !(e && e[0] == '0'); }();
+  static const int slab_wgs = [] { const char* e = std::getenv("XMCA_NT_SLAB_WGS"); return e ? std::atoi(e) : 2; }();
+  const int slots = nws.n_cus * (slab_wgs == 1 ? 1 : 2);
+  if (slab_on && tiles <= slots / 2 && (long long)nkt >= 64LL * (slots / tiles)) {
+    const int slabs = (int)(slots / tiles);
+    double* W = nws.partial.ensure((size_t)slabs * tiles * GEMM_BM * GEMM_BN);
+    GemmNtParams<TI, TO> p{A, B, C, M, N, K, lda, ldb, ldc, o.alpha, o.beta, o.row_scale, o.col_scale, o.upper_only ? 1 : 0, o.mirror,
+                           (int)tiles, map.dev.get(), nkt, total, nkt, W, vec_a, vec_b, slabs};
+    if (o.ev_begin) XMCA_HIP(hipEventRecord(o.ev_begin, st));
+    if (slab_wgs == 1) hipLaunchKernelGGL((gemm_nt_kernel<TI, TO, WIDE, 1>), dim3((unsigned)(slabs * tiles)), dim3(GEMM_THREADS), 0, st, p);
+    else hipLaunchKernelGGL((gemm_nt_kernel<TI, TO, WIDE, 2>), dim3((unsigned)(slabs * tiles)), dim3(GEMM_THREADS), 0, st, p);
+    if (o.ev_end) XMCA_HIP(hipEventRecord(o.ev_end, st));
+    hipLaunchKernelGGL((gemm_nt_slab_fixup_kernel<TO>), dim3((unsigned)tiles), dim3(256), 0, st, W, map.dev.get(), (int)tiles, slabs, C, M, N, ldc,
+                       o.alpha, o.beta, o.row_scale, o.col_scale, o.mirror);
+    XMCA_HIP(hipGetLastError());
+    return true;
+  }
+  const int max_wgs = nws.n_cus * NtCfg<TI>::WGS_PER_CU;
   // ranges: whole tiles when there are plenty of them (no partial segments at all), equal unit ranges otherwise
   int n_wg, upw;
   if (tiles >= 8LL * max_wgs) {
@@ -302,12 +365,10 @@ bool gemm_nt(hipStream_t st, GemmWorkspace& ws, GemmNtWorkspace& nws, const TI* 
     nws.key_tiles = tiles; nws.key_nkt = nkt; nws.key_upw = upw;
   }
   double* W = nws.n_split > 0 ? nws.partial.ensure((size_t)n_wg * 2 * GEMM_BM * GEMM_BN) : nullptr;
-  const int vec_a = (lda % VW == 0) && (reinterpret_cast<uintptr_t>(A) % 16 == 0);
-  const int vec_b = (ldb % VW == 0) && (reinterpret_cast<uintptr_t>(B) % 16 == 0);
   GemmNtParams<TI, TO> p{A, B, C, M, N, K, lda, ldb, ldc, o.alpha, o.beta, o.row_scale, o.col_scale, o.upper_only ? 1 : 0, o.mirror,
-                         (int)tiles, map.dev.get(), nkt, total, upw, W, vec_a, vec_b};
+                         (int)tiles, map.dev.get(), nkt, total, upw, W, vec_a, vec_b, 0};
   if (o.ev_begin) XMCA_HIP(hipEventRecord(o.ev_begin, st));
-  hipLaunchKernelGGL((gemm_nt_kernel<TI, TO, WIDE>), dim3(n_wg), dim3(GEMM_THREADS), 0, st, p);
+  hipLaunchKernelGGL((gemm_nt_kernel<TI, TO, WIDE, NtCfg<TI>::WGS_PER_CU>), dim3(n_wg), dim3(GEMM_THREADS), 0, st, p);
   if (o.ev_end) XMCA_HIP(hipEventRecord(o.ev_end, st));
   XMCA_HIP(hipGetLastError());
   if (nws.n_split > 0) {
