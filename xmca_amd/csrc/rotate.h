@@ -1262,7 +1262,7 @@ __global__ __launch_bounds__(256) void varimax_persistent_kernel(const double* _
                                                                  const double* __restrict__ A0r, const double* __restrict__ A0i,
                                                                  double* Rr, double* Ri, double* cvec, double* state, double* part_r,
                                                                  double* part_i, unsigned int* flags, double tol, int max_iter,
-                                                                 size_t work_doubles, int resident_tiles, double gamma) {
+                                                                 size_t work_doubles, int resident_tiles, double gamma, int poll_delay) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* sm = reinterpret_cast<double*>(smem_raw);          // accumulate / polar scratch (time-shared)
   const int pp = p * p, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1307,6 +1307,11 @@ __global__ __launch_bounds__(256) void varimax_persistent_kernel(const double* _
     if (tid == 0) __hip_atomic_store(flags + bid, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ROT_STAMP(6);
     if (wave == 0) {
+      // (the first poll waits: polling while the others still publish slows them down - measured on the tridiagonal
+      //  reduction's exchange, csrc/tridiag.h)
+      if (poll_delay >= 16) __builtin_amdgcn_s_sleep(16);
+      else if (poll_delay >= 8) __builtin_amdgcn_s_sleep(8);
+      else if (poll_delay >= 4) __builtin_amdgcn_s_sleep(4);
       unsigned int spins = 0;
       for (;;) {
         bool ok = true;

@@ -1358,12 +1358,13 @@ class Rotator {
       d.ppart_r.ensure((size_t)2 * d.nwg * p * p);
       if (CPLX) d.ppart_i.ensure((size_t)2 * d.nwg * p * p);
       XMCA_HIP(hipMemsetAsync(d.pflags.get(), 0, sizeof(unsigned int) * d.nwg, st));
+      const int rot_poll_delay = [] { const char* e = std::getenv("XMCA_ROT_POLL_DELAY"); return e ? std::atoi(e) : 0; }();   // (no measurable effect here: 0)
       XMCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(varimax_persistent_kernel<CPLX>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_smem));
       hipLaunchKernelGGL((varimax_persistent_kernel<CPLX>), dim3(d.nwg), dim3(256), persist_smem, st, d.A.r(), d.A.i(CPLX), d.h.get(),
                          d.N, p, d.A0.r(), d.A0.i(CPLX), d.R.r(), d.R.i(CPLX), d.cvec.get(), d.state.get(), d.ppart_r.get(),
                          CPLX ? d.ppart_i.get() : nullptr, d.pflags.get(), tol, persist_iters, work_bytes / sizeof(double),
-                         resident ? tiles_per_wg : 0, gamma);
+                         resident ? tiles_per_wg : 0, gamma, rot_poll_delay);
       XMCA_HIP(hipGetLastError());
       XMCA_HIP(hipMemcpyAsync(state, d.state.get(), sizeof(state), hipMemcpyDeviceToHost, st));
       XMCA_HIP(hipStreamSynchronize(st));

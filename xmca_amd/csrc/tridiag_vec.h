@@ -1,6 +1,6 @@
 // Eigenvectors for the tridiagonal route (tridiag.h):  A = Q T Q^H,  T y_k = lambda_k y_k,  u_k = Q y_k.
 //
-//   1. trd_twisted_kernel - one lane per eigenvalue: the two stationary factorisations of T - lambda_k I (forward L D+ L^T,
+//   1. trd_twisted_kernel - one lane pair per eigenvalue: the two stationary factorisations of T - lambda_k I (forward L D+ L^T,
 //      backward U D- U^T), the twist index r = argmin |gamma_r| and the vector z(r) = 1, z(i) = -(e_i / D+_i) z(i+1) upwards,
 //      z(i+1) = -(e_i / D-_{i+1}) z(i) downwards (Parlett & Dhillon; LAPACK dlar1v without the RRR shifts).  With an
 //      eigenvalue accurate to eps ||T|| the residual is eps ||T||; vectors of close eigenvalues are orthogonal only to
@@ -21,91 +21,121 @@
 namespace xmca {
 
 // Yt[i * ldy + k] = component i of the eigenvector of eigenvalue k (ascending);  W: work plane of the same shape.
-__global__ __launch_bounds__(64) void trd_twisted_kernel(const double* __restrict__ d, const double* __restrict__ e, int n,
+// 128 threads per 64 eigenvalues: the forward (D+) and the backward (D-) factorisation are independent recurrences and run
+// in the two waves side by side; so do the two halves of the vector (upwards / downwards from the twist index) and of the
+// final scaling.  Every loop requests 32 elements ahead of the recurrence (they are memory-latency bound otherwise).
+__global__ __launch_bounds__(128) void trd_twisted_kernel(const double* __restrict__ d, const double* __restrict__ e, int n,
                                                          const double* __restrict__ lam, double* __restrict__ W, double* __restrict__ Yt,
                                                          int64_t ldy) {
-  const int k = blockIdx.x * 64 + threadIdx.x;
-  if (k >= n) return;
-  const double l = lam[k];
-  if (n == 1) { Yt[k] = 1.0; return; }
+  __shared__ double nrm_sh[2][64];
+  const int lane = threadIdx.x & 63, half = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane;
+  const bool live = k < n;
+  const int kk = live ? k : n - 1;                           // (idle lanes shadow the last eigenvalue and store nothing)
+  const double l = lam[kk];
+  if (n == 1) { if (live && half == 0) Yt[k] = 1.0; return; }
+  constexpr int B = 32;
   double emax = 0.0;
   for (int i = 0; i < n - 1; ++i) emax = fmax(emax, fabs(e[i]));
   const double piv = 2.3e-308 * fmax(1.0, emax * emax) * 1e20 + 1e-300;
-  // forward: D+ into Yt
-  double dp = d[0] - l;
-  for (int i = 0; i < n - 1; ++i) {
+  if (half == 0) {
+    // forward: D+ into Yt
+    double dp = d[0] - l;
+    for (int i = 0; i < n - 1; ++i) {
+      if (!(fabs(dp) >= piv)) dp = dp < 0.0 ? -piv : piv;
+      if (live) Yt[(int64_t)i * ldy + k] = dp;
+      const double ei = e[i];
+      dp = (d[i + 1] - l) - (ei * trd_rcp(dp)) * ei;
+    }
     if (!(fabs(dp) >= piv)) dp = dp < 0.0 ? -piv : piv;
-    Yt[(int64_t)i * ldy + k] = dp;
-    const double ei = e[i];
-    dp = (d[i + 1] - l) - (ei * trd_rcp(dp)) * ei;
+    if (live) Yt[(int64_t)(n - 1) * ldy + k] = dp;
+  } else {
+    // backward: D- into W
+    double dm = d[n - 1] - l;
+    if (!(fabs(dm) >= piv)) dm = dm < 0.0 ? -piv : piv;
+    if (live) W[(int64_t)(n - 1) * ldy + k] = dm;
+    for (int i = n - 2; i >= 0; --i) {
+      const double ei = e[i];
+      dm = (d[i] - l) - (ei * trd_rcp(dm)) * ei;
+      if (!(fabs(dm) >= piv)) dm = dm < 0.0 ? -piv : piv;
+      if (live) W[(int64_t)i * ldy + k] = dm;
+    }
   }
-  if (!(fabs(dp) >= piv)) dp = dp < 0.0 ? -piv : piv;
-  Yt[(int64_t)(n - 1) * ldy + k] = dp;
-  // backward: D- into W, gamma_i = D+_i + D-_i - (d_i - lambda), twist at the smallest |gamma|.  The loads of D+ do
-  // not depend on the recurrence: 32 of them are requested at a time (the loops below are memory-latency bound).
-  constexpr int B = 32;
-  double dm = d[n - 1] - l;
-  int r = n - 1;
-  double gbest = fabs(dp + dm - (d[n - 1] - l));
-  if (!(fabs(dm) >= piv)) dm = dm < 0.0 ? -piv : piv;
-  W[(int64_t)(n - 1) * ldy + k] = dm;
-  for (int i0 = n - 2; i0 >= 0; i0 -= B) {
-    double yp[B];
+  __threadfence_block();
+  __syncthreads();
+  // twist index: gamma_i = D+_i + D-_i - (d_i - lambda), smallest |gamma| (both waves scan: no recurrence, pure streaming)
+  int r = 0;
+  {
+    double gbest = 1.7e308;
+    for (int i0 = 0; i0 < n; i0 += B) {
+      double yp[B], wm[B];
 #pragma unroll
-    for (int u = 0; u < B; ++u) yp[u] = i0 - u >= 0 ? Yt[(int64_t)(i0 - u) * ldy + k] : 0.0;
+      for (int u = 0; u < B; ++u) {
+        const int i = i0 + u < n ? i0 + u : n - 1;
+        yp[u] = Yt[(int64_t)i * ldy + kk];
+        wm[u] = W[(int64_t)i * ldy + kk];
+      }
 #pragma unroll
-    for (int u = 0; u < B; ++u) {
-      const int i = i0 - u;
-      if (i >= 0) {
-        const double ei = e[i];
-        dm = (d[i] - l) - (ei * trd_rcp(dm)) * ei;
-        const double g = fabs(yp[u] + dm - (d[i] - l));
-        if (g < gbest) { gbest = g; r = i; }
-        if (!(fabs(dm) >= piv)) dm = dm < 0.0 ? -piv : piv;
-        W[(int64_t)i * ldy + k] = dm;
+      for (int u = 0; u < B; ++u) {
+        const int i = i0 + u;
+        if (i < n) {
+          const double g = fabs(yp[u] + wm[u] - (d[i] - l));
+          if (g < gbest) { gbest = g; r = i; }
+        }
       }
     }
   }
-  // the vector
-  double z = 1.0, nrm = 1.0;
-  for (int i0 = r - 1; i0 >= 0; i0 -= B) {
-    double yp[B];
+  __syncthreads();                                           // (both waves have read D+ before the upper half overwrites it)
+  double nrm = 0.0;
+  if (half == 0) {
+    // upwards from the twist: z(i) = -(e_i / D+_i) z(i+1)
+    double z = 1.0;
+    nrm = 1.0;
+    if (live) Yt[(int64_t)r * ldy + k] = 1.0;
+    for (int i0 = r - 1; i0 >= 0; i0 -= B) {
+      double yp[B];
 #pragma unroll
-    for (int u = 0; u < B; ++u) yp[u] = i0 - u >= 0 ? Yt[(int64_t)(i0 - u) * ldy + k] : 1.0;
+      for (int u = 0; u < B; ++u) yp[u] = i0 - u >= 0 ? Yt[(int64_t)(i0 - u) * ldy + kk] : 1.0;
 #pragma unroll
-    for (int u = 0; u < B; ++u) {
-      const int i = i0 - u;
-      if (i >= 0) {
-        z = -(e[i] * trd_rcp(yp[u])) * z;
-        Yt[(int64_t)i * ldy + k] = z;
-        nrm += z * z;
+      for (int u = 0; u < B; ++u) {
+        const int i = i0 - u;
+        if (i >= 0) {
+          z = -(e[i] * trd_rcp(yp[u])) * z;
+          if (live) Yt[(int64_t)i * ldy + k] = z;
+          nrm += z * z;
+        }
+      }
+    }
+  } else {
+    // downwards: z(i+1) = -(e_i / D-_{i+1}) z(i)
+    double z = 1.0;
+    for (int i0 = r; i0 < n - 1; i0 += B) {
+      double wm[B];
+#pragma unroll
+      for (int u = 0; u < B; ++u) wm[u] = i0 + u < n - 1 ? W[(int64_t)(i0 + u + 1) * ldy + kk] : 1.0;
+#pragma unroll
+      for (int u = 0; u < B; ++u) {
+        const int i = i0 + u;
+        if (i < n - 1) {
+          z = -(e[i] * trd_rcp(wm[u])) * z;
+          if (live) Yt[(int64_t)(i + 1) * ldy + k] = z;
+          nrm += z * z;
+        }
       }
     }
   }
-  z = 1.0;
-  Yt[(int64_t)r * ldy + k] = 1.0;
-  for (int i0 = r; i0 < n - 1; i0 += B) {
-    double wm[B];
-#pragma unroll
-    for (int u = 0; u < B; ++u) wm[u] = i0 + u < n - 1 ? W[(int64_t)(i0 + u + 1) * ldy + k] : 1.0;
-#pragma unroll
-    for (int u = 0; u < B; ++u) {
-      const int i = i0 + u;
-      if (i < n - 1) {
-        z = -(e[i] * trd_rcp(wm[u])) * z;
-        Yt[(int64_t)(i + 1) * ldy + k] = z;
-        nrm += z * z;
-      }
-    }
-  }
-  const double s = 1.0 / sqrt(nrm);
-  for (int i0 = 0; i0 < n; i0 += B) {
+  nrm_sh[half][lane] = nrm;
+  __threadfence_block();
+  __syncthreads();
+  const double s = 1.0 / sqrt(nrm_sh[0][lane] + nrm_sh[1][lane]);
+  const int h0 = half == 0 ? 0 : n / 2, h1 = half == 0 ? n / 2 : n;
+  for (int i0 = h0; i0 < h1; i0 += B) {
     double y[B];
 #pragma unroll
-    for (int u = 0; u < B; ++u) y[u] = i0 + u < n ? Yt[(int64_t)(i0 + u) * ldy + k] : 0.0;
+    for (int u = 0; u < B; ++u) y[u] = i0 + u < h1 ? Yt[(int64_t)(i0 + u) * ldy + kk] : 0.0;
 #pragma unroll
     for (int u = 0; u < B; ++u)
-      if (i0 + u < n) Yt[(int64_t)(i0 + u) * ldy + k] = y[u] * s;
+      if (live && i0 + u < h1) Yt[(int64_t)(i0 + u) * ldy + k] = y[u] * s;
   }
 }
 
@@ -242,7 +272,7 @@ inline bool trd_eigenvectors(hipStream_t st, TrdWorkspace& ws, TrdVecWorkspace& 
   double* Yi = cplx ? vw.Y[1].ensure(plane) : nullptr;
   double* Wr = vw.Wk[0].ensure(plane);
   double* Wi = cplx ? vw.Wk[1].ensure(plane) : nullptr;
-  hipLaunchKernelGGL(trd_twisted_kernel, dim3(ceil_div(n, 64)), dim3(64), 0, st, P.d, P.e, n, vw.lam_asc.get(), Wr, Yr, ld);
+  hipLaunchKernelGGL(trd_twisted_kernel, dim3(ceil_div(n, 64)), dim3(128), 0, st, P.d, P.e, n, vw.lam_asc.get(), Wr, Yr, ld);
   XMCA_HIP(hipGetLastError());
   if (cplx) XMCA_HIP(hipMemsetAsync(Yi, 0, sizeof(double) * plane, st));
   // ---- Z = H_0 H_1 ... H_{n-2} Yt, blocks of 64 reflectors from the last to the first:  Z -= V (T (V^H Z)) ----
