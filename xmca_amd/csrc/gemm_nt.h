@@ -327,7 +327,8 @@ bool gemm_nt(hipStream_t st, GemmWorkspace& ws, GemmNtWorkspace& nws, const TI* 
   static const int slab_wgs = [] { const char* e = std::getenv("XMCA_NT_SLAB_WGS"); return e ? std::atoi(e) : 2; }();
   const int slots = nws.n_cus * (slab_wgs == 1 ? 1 : 2);
   if (slab_on && tiles <= slots / 2 && (long long)nkt >= 64LL * (slots / tiles)) {
-    const int slabs = (int)(slots / tiles);
+    static const int slabs_forced = [] { const char* e = std::getenv("XMCA_NT_SLAB_COUNT"); return e ? std::atoi(e) : 0; }();
+    const int slabs = slabs_forced > 0 ? slabs_forced : (int)(slots / tiles);
     double* W = nws.partial.ensure((size_t)slabs * tiles * GEMM_BM * GEMM_BN);
     GemmNtParams<TI, TO> p{A, B, C, M, N, K, lda, ldb, ldc, o.alpha, o.beta, o.row_scale, o.col_scale, o.upper_only ? 1 : 0, o.mirror,
                            (int)tiles, map.dev.get(), nkt, total, nkt, W, vec_a, vec_b, slabs};
