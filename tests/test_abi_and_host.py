@@ -228,3 +228,14 @@ def test_lazy_vectors_and_raw_field_stand_in():
     f.ops.append((False, w))
     want = (raw[:, keep] - raw[:, keep].mean(axis=0)) / raw[:, keep].std(axis=0) * w
     assert np.allclose(f.centered(), want, rtol=1e-14, atol=1e-14)
+
+
+def test_plot_methods_exist_and_say_what_to_use_instead():
+    """the reference exposes plot / save_plot on both classes (xmca/array.py:1430, xarray.py): here they exist and raise a
+    NotImplementedError that names the getters to plot from - not an AttributeError."""
+    import pytest
+    from xmca_amd.array import MCA
+    m = MCA()
+    for fn in (m.plot, m.save_plot):
+        with pytest.raises(NotImplementedError, match="eofs"):
+            fn(mode=1)

@@ -1076,6 +1076,15 @@ class MCA:
                         continue                      # the file's writer, not this package
                     self._set_analysis(key, line.split(':')[1].strip())
 
+    def plot(self, *args, **kwargs):
+        """Not part of the accelerated path (xmca/array.py:1430-1711 draws with matplotlib / cartopy): every number the
+        reference's figure shows is available from `eofs()`, `pcs()`, `explained_variance()`."""
+        raise NotImplementedError('xmca_amd does not draw: plot()/save_plot() of the reference need matplotlib and cartopy; '
+                                  'use eofs(), pcs(), explained_variance() of this model with your own plotting code')
+
+    def save_plot(self, *args, **kwargs):
+        return self.plot(*args, **kwargs)
+
     def load_analysis(self, path, fields=None, eofs=None, singular_values=None):
         """Restore a model written by `save_analysis` (fields / eofs / singular values supplied by the caller)."""
         self._set_info_from_file(path)

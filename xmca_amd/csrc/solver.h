@@ -2,6 +2,7 @@
 // rotate (Varimax / Promax) and the Rule-N surrogate loop.  Formulation and reference line numbers:
 // DESIGN.md sections 2-4.
 #pragma once
+#include <atomic>
 #include <complex>
 #include <map>
 #include <memory>
@@ -1349,7 +1350,22 @@ class Rotator {
       if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
       return n;
     }();
-    if (fused && persist_on && persist_smem <= 160 * 1024 && d.nwg <= 256 && d.nwg <= n_cus && max_iter > 0) {
+    // ... and so must the persistent grids of the OTHER surrogate lanes of this process (rule_n / bootstrap keep several
+    // replicates in flight): a process-wide budget of workgroups in flight; a launch that would exceed the CU count takes
+    // the per-iteration launches instead of relying on the bounded spins
+    static std::atomic<int> persist_inflight{0};
+    bool persist_ok = fused && persist_on && persist_smem <= 160 * 1024 && d.nwg <= 256 && d.nwg <= n_cus && max_iter > 0;
+    if (persist_ok) {
+      if (persist_inflight.fetch_add(d.nwg) + d.nwg > n_cus) {
+        persist_inflight.fetch_sub(d.nwg);
+        persist_ok = false;
+      }
+    }
+    struct InflightGuard {
+      std::atomic<int>& c; int n; bool on;
+      ~InflightGuard() { if (on) c.fetch_sub(n); }
+    } inflight_guard{persist_inflight, d.nwg, persist_ok};
+    if (persist_ok) {
       // XMCA_VARIMAX_TEST_GIVEUP=k (tests): the persistent launch stops after k iterations, as if a workgroup had gone
       // missing there, and the per-iteration launches take over - the hand-over must not change R or the stop iteration
       const char* tg = std::getenv("XMCA_VARIMAX_TEST_GIVEUP");

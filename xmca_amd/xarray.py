@@ -216,6 +216,13 @@ class xMCA(MCA):
         out = os.path.join(path, secure_str('.'.join([data.name, 'nc'])))
         data.to_netcdf(path=out, engine=engine, invalid_netcdf=(engine == 'h5netcdf'), *args, **kwargs)
 
+    def plot(self, *args, **kwargs):
+        """see `xmca_amd.array.MCA.plot`"""
+        return MCA.plot(self, *args, **kwargs)
+
+    def save_plot(self, *args, **kwargs):
+        return MCA.plot(self, *args, **kwargs)
+
     def save_analysis(self, path=None, engine='h5netcdf'):
         """info.xmca + original-scale real fields, UNROTATED eofs and singular values (xarray.py:1253-1279)."""
         path = self._get_analysis_path(path)
