@@ -31,7 +31,39 @@ import subprocess
 import sys
 import time
 
-import numpy as np
+
+def _cap_host_threads():
+    """BLAS/OpenMP threads = the CPUs this container may actually use.  The GPU boxes show 256 cores but run under a cgroup
+    quota of 16: a BLAS call with one spinning thread per core exhausts the quota and the kernel then stalls every thread of
+    the process - including the one waiting for the device - for 50-80 ms at a time (measured: nr_throttled in cpu.stat)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(parts[0]) // int(parts[1])))
+            else:
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    per = int(f.read())
+                if int(parts[0]) > 0:
+                    n = min(n, max(1, int(parts[0]) // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    for v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ.setdefault(v, str(n))
+    return n
+
+
+HOST_THREADS = _cap_host_threads()          # before numpy / torch load their thread pools
+
+import numpy as np   # noqa: E402
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
@@ -369,7 +401,7 @@ def main():
         t1 = time.perf_counter()
         r = O.rotate(o["V"], o["singular_values"], args.n_rot, args.power)
         t2 = time.perf_counter()
-        cpu = {"value": 1.0 / (t2 - t0), "unit": "solve+rotate/s", "cores": os.cpu_count(), "kind": "port",
+        cpu = {"value": 1.0 / (t2 - t0), "unit": "solve+rotate/s", "cores": HOST_THREADS, "kind": "port",
                "sample": "1 full solve()+rotate() of the same C2 input (numpy oracle: gesdd per field, kernel, gesdd, "
                          "back-projection, Varimax loop)",
                "solve_ms": 1e3 * (t1 - t0), "rotate_ms": 1e3 * (t2 - t1), "varimax_iterations": int(r["n_iter"])}

@@ -30,6 +30,6 @@ for n in sizes:
         lam, _ = h.eigh(G, vectors=False)
         wall = time.perf_counter() - t0
         tm = h.timings()
-        rec.update(err=float(np.max(np.abs(lam - ref)) / ref[0]), ms=tm.get("eigh_values"), wall_ms=wall * 1e3, info=h.last_eigh_info)
+        rec.update(err=float(np.max(np.abs(lam - ref)) / ref[0]), ms=tm.get("eigh_values"), wall_ms=wall * 1e3, info=h.last_eigh_info, trd={k: round(v, 3) for k, v in tm.items() if k.startswith("trd")})
         out.append(rec)
         print(json.dumps(rec), flush=True)

@@ -3,8 +3,8 @@ factorisation vectors, blocked back-transformation, Newton-Schulz clean-up) - cs
 replaces LAPACK's *gesdd / eigh on the T x T stage of xmca/array.py:479 and :570 for eigenproblems of 192 (values only) /
 768 (with vectors) and more.  Everything against numpy.linalg.eigh / eigvalsh on the same matrices:
 
-* both forms of the reduction - one launch per column, and the persistent kernel with the matrix resident in registers -
-  real and complex, sizes around the chunk / row-slot boundaries of the kernels;
+* both forms of the reduction - one launch per column, and the persistent kernel with the matrix resident in registers
+  (its column exchange by tagged values and by epoch flags) - real and complex, sizes around the chunk / row-slot boundaries of the kernels;
 * spectra the twisted vectors cannot resolve (repeated eigenvalues, wide null spaces) come back through the Jacobi sweeps;
 * bit-reproducibility (every sum has a fixed order) and NaN input -> LinAlgError like gesdd.
 """
@@ -24,12 +24,19 @@ def _gram(n, cplx, seed=None, spikes=20):
     return X @ X.conj().T
 
 
-@pytest.mark.parametrize("resident", ["1", "0"])
+def _reduction_form(monkeypatch, form):
+    """"0": one launch per column; "tagged" / "flags": the persistent kernel with either form of its column exchange"""
+    monkeypatch.setenv("XMCA_TRD_RESIDENT", "0" if form == "0" else "1")
+    if form != "0":
+        monkeypatch.setenv("XMCA_TRD_TAGGED", "1" if form == "tagged" else "0")
+
+
+@pytest.mark.parametrize("resident", ["tagged", "flags", "0"])
 @pytest.mark.parametrize("n,cplx", [(2, False), (3, True), (64, False), (127, True), (129, False), (385, False), (512, True), (1000, False),
                                     (1025, True), (1100, False), (2049, False), (2100, True)])
 def test_eigenvalues_only_match_lapack(hip, monkeypatch, n, cplx, resident):
     monkeypatch.setenv("XMCA_TRIDIAG_MIN_N", "2")
-    monkeypatch.setenv("XMCA_TRD_RESIDENT", resident)
+    _reduction_form(monkeypatch, resident)
     monkeypatch.setenv("XMCA_TRD_RESIDENT_MIN_N", "2")
     G = _gram(n, cplx)
     lam, U = hip.eigh(G, vectors=False)
@@ -40,11 +47,11 @@ def test_eigenvalues_only_match_lapack(hip, monkeypatch, n, cplx, resident):
     assert np.array_equal(lam, again)                       # fixed summation order: the same bits
 
 
-@pytest.mark.parametrize("resident", ["1", "0"])
+@pytest.mark.parametrize("resident", ["tagged", "flags", "0"])
 @pytest.mark.parametrize("n,cplx", [(70, False), (200, True), (777, False), (1000, True), (1500, False)])
 def test_eigenvectors_match_lapack(hip, monkeypatch, n, cplx, resident):
     monkeypatch.setenv("XMCA_TRIDIAG_VEC_MIN_N", "2")
-    monkeypatch.setenv("XMCA_TRD_RESIDENT", resident)
+    _reduction_form(monkeypatch, resident)
     monkeypatch.setenv("XMCA_TRD_RESIDENT_MIN_N", "2")
     G = _gram(n, cplx)
     lam, U = hip.eigh(G)

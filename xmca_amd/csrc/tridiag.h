@@ -426,11 +426,27 @@ struct TrdSync {
   int poll_delay;         // 64-cycle units to sleep before the first poll (polling early only disturbs the publishers)
 };
 
+
 __device__ __forceinline__ double trd_ld_sc1(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void trd_st_sc1(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// Tagged exchange (TAG instantiations): the lowest mantissa bit of every published double carries the epoch tag of the
+// column that consumes it, so a value is its own flag - no drain, no flag store, no poll, no partial sums: a consumer asks
+// again for exactly the values whose tag is still the old one.  Buffers alternate with the column parity, so the value a slot
+// held before is the one of two columns ago: tag(j) = ((j + 1) >> 1) & 1 differs between the two, and the first use of each
+// buffer expects 1 over the zero-filled memory.  The tag bit is cleared on arrival: every workgroup sees the same p and
+// row j, rounded down by at most one ulp - below the rounding of the products they come from.
+__device__ __forceinline__ unsigned int trd_tag_of(int j) { return ((unsigned int)(j + 1) >> 1) & 1u; }
+__device__ __forceinline__ double trd_tagged(double v, unsigned int tag) {
+  return __hiloint2double(__double2hiint(v), (int)(((unsigned int)__double2loint(v) & ~1u) | tag));
+}
+__device__ __forceinline__ bool trd_tag_is(double v, unsigned int tag) { return ((unsigned int)__double2loint(v) & 1u) == tag; }
+__device__ __forceinline__ double trd_untagged(double v) {
+  return __hiloint2double(__double2hiint(v), (int)((unsigned int)__double2loint(v) & ~1u));
+}
+
 constexpr int TRD_RES_THREADS = 256;   // one wave per SIMD: 512 registers per lane for the resident rows
-template <bool CPLX, int NC, int RR>
+template <bool CPLX, int NC, int RR, bool TAG>
 __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams P, TrdSync S, int first_res) {
   extern __shared__ __attribute__((aligned(16))) double trd_lds[];
   __shared__ double red[TRD_RES_THREADS / 64];
@@ -489,10 +505,11 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
     // zero-filled before the launch and hold row 0 in rowbuf[0]: column 0 needs no special case) ----
     const double* const prr = pub_r[prev];
     const double* const pri = pub_i[prev];
-    const double* const rwr = rb_r[cur];
-    const double* const rwi = rb_i[cur];
+    // (tagged exchange: row 0 comes from the working copy - a prefilled buffer would carry arbitrary tag bits into column 2)
+    const double* const rwr = (TAG && j == 0) ? P.Ar : rb_r[cur];
+    const double* const rwi = (TAG && j == 0 && CPLX) ? P.Ai : rb_i[cur];
     double gr = 0.0, gi = 0.0;
-    if (tid < nwg) {
+    if (!TAG && tid < nwg) {
       gr = trd_ld_sc1(gp_r[prev] + tid);
       if (CPLX) gi = trd_ld_sc1(gp_i[prev] + tid);
     }
@@ -509,8 +526,57 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
         lq_[t] = trd_ld_sc1(pri + k);
       }
     }
+    if constexpr (TAG) {
+      // wait for the values of column j (tag), each thread for its own slots; p^H v from every workgroup's own copy of v_{j-1}
+      const unsigned int tg = trd_tag_of(j);
+      if (j > 0) {
+        unsigned int spins = 0;
+        for (;;) {
+          bool all = true;
+#pragma unroll
+          for (int t = 0; t < NS; ++t) {
+            const int k = tid + t * TRD_RES_THREADS;
+            if (k >= j && k < n) {
+              bool ok = trd_tag_is(lr_[t], tg) && trd_tag_is(lp_[t], tg);
+              if (CPLX) ok = ok && trd_tag_is(li_[t], tg) && trd_tag_is(lq_[t], tg);
+              if (!ok) {
+                all = false;
+                lr_[t] = trd_ld_sc1(rwr + k);
+                lp_[t] = trd_ld_sc1(prr + k);
+                if (CPLX) {
+                  li_[t] = trd_ld_sc1(rwi + k);
+                  lq_[t] = trd_ld_sc1(pri + k);
+                }
+              }
+            }
+          }
+          if (__all(all)) break;
+          if (++spins > (1u << 17)) { give_up_sh = 1; break; }       // (~0.2 s) a workgroup is missing: report, never hang
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < NS; ++t) {
+        const int k = tid + t * TRD_RES_THREADS;
+        lr_[t] = trd_untagged(lr_[t]);
+        lp_[t] = trd_untagged(lp_[t]);
+        if (CPLX) {
+          li_[t] = trd_untagged(li_[t]);
+          lq_[t] = trd_untagged(lq_[t]);
+        }
+        if (k >= j && k < n) {
+          const double vr = bV[0][k], vi = CPLX ? bV[1][k] : 0.0;
+          gr += lp_[t] * vr + lq_[t] * vi;              // conj(p) v
+          gi += lp_[t] * vi - lq_[t] * vr;
+        }
+      }
+    }
     gr = trd_block_sum_n<TRD_RES_THREADS / 64>(gr, red);
     if (CPLX) gi = trd_block_sum_n<TRD_RES_THREADS / 64>(gi, red);
+    if (TAG && give_up_sh) {
+      if (tid == 0) atomicExch(S.give_up, 1);
+      break;
+    }
     const double ar_ = -0.5 * (tpr * gr - tpi * gi);
     const double ai_ = -0.5 * (tpr * gi + tpi * gr);
     // w_{j-1} = p_{j-1} + alpha v_{j-1};  conj(row j) parked in bX.  Slots outside [j, n) are written as zeros: dead columns
@@ -633,6 +699,7 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
     double* const pbi = pub_i[cur];
     double* const nrr = rb_r[prev];
     double* const nri = rb_i[prev];
+    const unsigned int tgn = trd_tag_of(j + 1);      // what is published now is consumed by column j+1
     // early rows (i < first_res, owner wave i mod NW): the same from global memory - first, so that their stores are on
     // their way while the resident rows are processed (the drain before the flag waits for every store of the wave)
     {
@@ -682,8 +749,8 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
                 sr += a.y * xk.y - b.y * xki.y;
                 si += a.y * xki.y + b.y * xk.y;
                 if (pubrow) {
-                  trd_st_sc1(nri + k, b.x);
-                  trd_st_sc1(nri + k + 1, b.y);
+                  trd_st_sc1(nri + k, TAG ? trd_tagged(b.x, tgn) : b.x);
+                  trd_st_sc1(nri + k + 1, TAG ? trd_tagged(b.y, tgn) : b.y);
                 }
               } else {
                 a.x -= svr_ * wk.x + swr_ * vk.x;
@@ -693,8 +760,8 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
                 sr += a.y * xk.y;
               }
               if (pubrow) {
-                trd_st_sc1(nrr + k, a.x);
-                trd_st_sc1(nrr + k + 1, a.y);
+                trd_st_sc1(nrr + k, TAG ? trd_tagged(a.x, tgn) : a.x);
+                trd_st_sc1(nrr + k + 1, TAG ? trd_tagged(a.y, tgn) : a.y);
               }
             }
           }
@@ -704,8 +771,8 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
         const double pr = tr * yr - ti * yi, pi = tr * yi + ti * yr;
         const double vr = bX[0][i], vi = CPLX ? bX[1][i] : 0.0;
         if (lane == 0) {
-          trd_st_sc1(pbr + i, pr);
-          if (CPLX) trd_st_sc1(pbi + i, pi);
+          trd_st_sc1(pbr + i, TAG ? trd_tagged(pr, tgn) : pr);
+          if (CPLX) trd_st_sc1(pbi + i, TAG ? trd_tagged(pi, tgn) : pi);
         }
         gwr += pr * vr + pi * vi;
         gwi += pr * vi - pi * vr;
@@ -774,8 +841,8 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
           const double pr = tr * yr - ti * yi, pi = tr * yi + ti * yr;
           const double vr = bX[0][i], vi = CPLX ? bX[1][i] : 0.0;
           if (lane == 0) {
-            trd_st_sc1(pbr + i, pr);
-            if (CPLX) trd_st_sc1(pbi + i, pi);
+            trd_st_sc1(pbr + i, TAG ? trd_tagged(pr, tgn) : pr);
+            if (CPLX) trd_st_sc1(pbi + i, TAG ? trd_tagged(pi, tgn) : pi);
           }
           gwr += pr * vr + pi * vi;
           gwi += pr * vi - pi * vr;
@@ -784,11 +851,11 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
             for (int c = 0; c < NC; ++c) {
               if (c >= c0) {
                 const int k = 128 * c + 2 * lane;
-                trd_st_sc1(nrr + k, ar[t][c].x);
-                trd_st_sc1(nrr + k + 1, ar[t][c].y);
+                trd_st_sc1(nrr + k, TAG ? trd_tagged(ar[t][c].x, tgn) : ar[t][c].x);
+                trd_st_sc1(nrr + k + 1, TAG ? trd_tagged(ar[t][c].y, tgn) : ar[t][c].y);
                 if (CPLX) {
-                  trd_st_sc1(nri + k, ai[t][c].x);
-                  trd_st_sc1(nri + k + 1, ai[t][c].y);
+                  trd_st_sc1(nri + k, TAG ? trd_tagged(ai[t][c].x, tgn) : ai[t][c].x);
+                  trd_st_sc1(nri + k + 1, TAG ? trd_tagged(ai[t][c].y, tgn) : ai[t][c].y);
                 }
               }
             }
@@ -797,38 +864,40 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
       }
     }
     if (prof) P.prof[8 * j + 4] = __builtin_amdgcn_s_memtime();
-    if (lane == 0) {
-      gam_sh[wave][0] = gwr;
-      gam_sh[wave][1] = gwi;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      double sr = 0.0, si = 0.0;
-#pragma unroll
-      for (int w = 0; w < TRD_RES_THREADS / 64; ++w) { sr += gam_sh[w][0]; si += gam_sh[w][1]; }
-      trd_st_sc1(gp_r[cur] + blockIdx.x, sr);
-      if (CPLX) trd_st_sc1(gp_i[cur] + blockIdx.x, si);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every storing wave drains before the flag goes out
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(flags + blockIdx.x, (unsigned int)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (prof) P.prof[8 * j + 5] = __builtin_amdgcn_s_memtime();
-    // ---- exchange: wait until every workgroup has published column j ----
-    if (wave == 0) {
-      // the first poll waits ~1000 cycles: polling while the other workgroups still publish only slows them down (measured:
-      // n = 2920 26.9 -> 25.2 ms; counting arrivals in 8 sharded counters instead of 256 flags: 32 ms)
-      if (S.poll_delay >= 32) __builtin_amdgcn_s_sleep(32);
-      else if (S.poll_delay >= 16) __builtin_amdgcn_s_sleep(16);
-      else if (S.poll_delay >= 8) __builtin_amdgcn_s_sleep(8);
-      else if (S.poll_delay >= 4) __builtin_amdgcn_s_sleep(4);
-      unsigned int spins = 0;
-      for (;;) {
-        bool ok = true;
-        for (int w = lane; w < nwg; w += 64)
-          ok &= __hip_atomic_load(flags + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned int)(j + 1);
-        if (__all(ok)) break;
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1u << 17)) { if (lane == 0) give_up_sh = 1; break; }     // (~0.2 s) a workgroup is missing: report, never hang
+    if constexpr (!TAG) {
+      if (lane == 0) {
+        gam_sh[wave][0] = gwr;
+        gam_sh[wave][1] = gwi;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        double sr = 0.0, si = 0.0;
+  #pragma unroll
+        for (int w = 0; w < TRD_RES_THREADS / 64; ++w) { sr += gam_sh[w][0]; si += gam_sh[w][1]; }
+        trd_st_sc1(gp_r[cur] + blockIdx.x, sr);
+        if (CPLX) trd_st_sc1(gp_i[cur] + blockIdx.x, si);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every storing wave drains before the flag goes out
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(flags + blockIdx.x, (unsigned int)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (prof) P.prof[8 * j + 5] = __builtin_amdgcn_s_memtime();
+      // ---- exchange: wait until every workgroup has published column j ----
+      if (wave == 0) {
+        // the first poll waits ~1000 cycles: polling while the other workgroups still publish only slows them down (measured:
+        // n = 2920 26.9 -> 25.2 ms; counting arrivals in 8 sharded counters instead of 256 flags: 32 ms)
+        if (S.poll_delay >= 32) __builtin_amdgcn_s_sleep(32);
+        else if (S.poll_delay >= 16) __builtin_amdgcn_s_sleep(16);
+        else if (S.poll_delay >= 8) __builtin_amdgcn_s_sleep(8);
+        else if (S.poll_delay >= 4) __builtin_amdgcn_s_sleep(4);
+        unsigned int spins = 0;
+        for (;;) {
+          bool ok = true;
+          for (int w = lane; w < nwg; w += 64)
+            ok &= __hip_atomic_load(flags + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned int)(j + 1);
+          if (__all(ok)) break;
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1u << 17)) { if (lane == 0) give_up_sh = 1; break; }     // (~0.2 s) a workgroup is missing: report, never hang
+        }
       }
     }
     __syncthreads();
@@ -1116,13 +1185,25 @@ inline TrdParams trd_reduce(hipStream_t st, TrdWorkspace& ws, const double* Ar, 
     S.flags = ws.flags.get();
     { const char* e = std::getenv("XMCA_TRD_POLL_DELAY"); S.poll_delay = e ? std::atoi(e) : 16; }
     // column 0 reads its row like every other column: from rowbuf (parity 0)
-    XMCA_HIP(hipMemcpyAsync(S.rowbuf[0][0], P.Ar, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
-    if (cplx) XMCA_HIP(hipMemcpyAsync(S.rowbuf[0][1], P.Ai, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
+    // (the tagged form reads row 0 from the working copy: the exchange buffers must start as zeros)
+    // exchange by tagged values or by epoch flags.  Measured (n = 2920 real / 2501 complex): tagged 24.9 / 36.7 ms, flags 25.4 /
+    // 32.6 ms - four planes per slot have to arrive for a complex column - so: real problems tagged, complex ones flags
+    // (XMCA_TRD_TAGGED=1 / 0 forces one form for both)
+    const bool tagged = [cplx] { const char* e = std::getenv("XMCA_TRD_TAGGED"); return e ? e[0] != '0' : !cplx; }();
+    if (!tagged) {
+      XMCA_HIP(hipMemcpyAsync(S.rowbuf[0][0], P.Ar, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
+      if (cplx) XMCA_HIP(hipMemcpyAsync(S.rowbuf[0][1], P.Ai, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
+    }
     S.give_up = reinterpret_cast<int*>(ws.flags.get() + TRD_MAX_WGS);
     using ResFn = void (*)(TrdParams, TrdSync, int);
     ResFn fn = nullptr;
-    if (cplx) fn = nc == 8 ? trd_resident_kernel<true, 8, 1> : nc == 16 ? trd_resident_kernel<true, 16, 2> : trd_resident_kernel<true, 20, 2>;
-    else fn = nc == 8 ? trd_resident_kernel<false, 8, 1> : nc == 16 ? trd_resident_kernel<false, 16, 2> : trd_resident_kernel<false, 24, 3>;
+    if (tagged) {
+      if (cplx) fn = nc == 8 ? trd_resident_kernel<true, 8, 1, true> : nc == 16 ? trd_resident_kernel<true, 16, 2, true> : trd_resident_kernel<true, 20, 2, true>;
+      else fn = nc == 8 ? trd_resident_kernel<false, 8, 1, true> : nc == 16 ? trd_resident_kernel<false, 16, 2, true> : trd_resident_kernel<false, 24, 3, true>;
+    } else {
+      if (cplx) fn = nc == 8 ? trd_resident_kernel<true, 8, 1, false> : nc == 16 ? trd_resident_kernel<true, 16, 2, false> : trd_resident_kernel<true, 20, 2, false>;
+      else fn = nc == 8 ? trd_resident_kernel<false, 8, 1, false> : nc == 16 ? trd_resident_kernel<false, 16, 2, false> : trd_resident_kernel<false, 24, 3, false>;
+    }
     const size_t lds = lv * 3 * (cplx ? 2 : 1) * sizeof(double);
     XMCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     static const char* prof_file_r = std::getenv("XMCA_TRD_PROF");
