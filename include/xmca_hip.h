@@ -41,7 +41,7 @@ typedef struct xmca_handle xmca_handle;
 /* library / device management ------------------------------------------------------------------------- */
 const char* xmca_version(void);
 /* Number of this header's ABI (XMCA_ABI_VERSION): the binding refuses a library built from another revision. */
-#define XMCA_ABI_VERSION 5
+#define XMCA_ABI_VERSION 6
 int xmca_abi_version(void);
 int xmca_device_count(void);
 int xmca_create(int device, xmca_handle** out);
@@ -149,6 +149,13 @@ int xmca_get_solve_info(xmca_handle* h, int* info, int n);
 int xmca_rotate_loadings(xmca_handle* h, const double* L, int64_t N, int64_t n_left, int p, int is_complex, int power,
                          double tol, int max_iter, int varimax_only, double gamma, double* B_out, double* R_out,
                          double* Phi_out, double* norm_left, double* norm_right, int* iters_out);
+
+/* MCA.rotate (xmca/array.py:815-833) on the result of the last xmca_solve, without the vectors leaving the device: the
+ * loadings V sqrt(sigma) of both fields are stacked (array.py:818-822) from the resident singular vectors, then as
+ * xmca_rotate_loadings (full Promax, gamma = 1).  p <= the number of back-projected modes.  Outputs as there
+ * (is_complex = xmca_is_complex(h)); XMCA_ERR_NOT_CONVERGED / XMCA_ERR_NUMERIC as there. */
+int xmca_rotate_solved(xmca_handle* h, int p, int power, double tol, int max_iter, double* R_out, double* Phi_out,
+                       double* norm_left, double* norm_right, int* iters_out);
 
 /* MCA.rule_n surrogate loop (xmca/array.py:1753-1765) for runs [run_begin, run_end): N(0,1) surrogates
  * (Philox4x32-10 keyed by seed, run, side) generated on the device, centered, optionally complexified

@@ -53,7 +53,9 @@ def main():
         h.reset_timings()
         t0 = time.perf_counter(); m.solve(complexify=True); out["solve_s"] = time.perf_counter() - t0
         out["stages_ms"] = h.timings(); out["evd"] = h.solve_info()
+        h.reset_timings()
         t0 = time.perf_counter(); m.rotate(20, 4); out["rotate_s"] = time.perf_counter() - t0
+        out["rotate_stages_ms"] = h.timings()
         out["varimax_iterations"] = m._varimax_iterations
         k = 10
         t0 = time.perf_counter()

@@ -59,7 +59,7 @@ def test_shapes_like_reference_unit_test():
     assert eofs['left'].shape == left.shape[1:] + (rank,)
     assert eofs['right'].shape == right.shape[1:] + (rank,)
     assert m._analysis['rank'] == rank and m._analysis['n_rot'] == rank
-    assert np.array_equal(m._rotation_matrix, np.eye(rank))
+    assert np.array_equal(m.rotation_matrix(), np.eye(rank)) and np.array_equal(m.correlation_matrix(), np.eye(rank))
 
 
 def test_getters_before_solve_raise():

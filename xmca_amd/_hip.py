@@ -50,6 +50,7 @@ SIGNATURES = {
     "xmca_get_solve_info": (_c_int, [_vp, _vp, _c_int]),
     "xmca_rotate_loadings": (_c_int, [_vp, _vp, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_dbl, _c_int, _c_int, _c_dbl,
                                       _vp, _vp, _vp, _vp, _vp, _ip]),
+    "xmca_rotate_solved": (_c_int, [_vp, _c_int, _c_int, _c_dbl, _c_int, _vp, _vp, _vp, _vp, _ip]),
     "xmca_rule_n": (_c_int, [_vp, _c_i64, _c_i64, _c_i64, _c_int, _vp, _c_int, _c_int, _c_int, _c_dbl, _c_i64, _c_i64,
                              ctypes.c_uint64, _c_int, _vp, _vp, _c_i64]),
     "xmca_surrogate": (_c_int, [_vp, _c_i64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _vp]),
@@ -73,7 +74,7 @@ def library_path():
     return _build.LIB
 
 
-ABI_VERSION = 5          # bumped whenever a signature of include/xmca_hip.h changes; checked against xmca_abi_version()
+ABI_VERSION = 6          # bumped whenever a signature of include/xmca_hip.h changes; checked against xmca_abi_version()
 
 
 def load_library():
@@ -367,6 +368,25 @@ class Handle:
         self.last_iters = int(iters.value)
         self._check(rc)
         return {"B": B, "R": R, "Phi": Phi, "norm_left": nl, "norm_right": nr, "n_iter": int(iters.value)}
+
+    def rotate_solved(self, p, power=1, tol=1e-8, max_iter=1000):
+        """MCA.rotate on the resident result of the last solve (the loadings are built on the device)."""
+        cplx = bool(self._lib.xmca_is_complex(self._h))
+        cdt = np.complex128 if cplx else np.float64
+        R = np.empty((p, p), dtype=cdt)
+        Phi = np.empty((p, p), dtype=cdt)
+        nl = np.zeros(p)
+        nr = np.zeros(p)
+        iters = _c_int(0)
+        rc = self._lib.xmca_rotate_solved(self._h, int(p), int(power), float(tol), int(max_iter), _ptr(R), _ptr(Phi), _ptr(nl),
+                                          _ptr(nr), ctypes.byref(iters))
+        self.last_iters = int(iters.value)
+        self._check(rc)
+        return {"B": None, "R": R, "Phi": Phi, "norm_left": nl, "norm_right": nr, "n_iter": int(iters.value)}
+
+    def holds_result_of(self, holder):
+        ref = getattr(self, "_result_holder", None)
+        return ref is not None and ref() is holder
 
     # ---- rule N -------------------------------------------------------------------------------
     def rule_n(self, T, Nx, Ny, n_fields, complexify, rotated, p, power, tol, run_begin, run_end, seed, dtype, n_out):

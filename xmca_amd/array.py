@@ -514,8 +514,11 @@ class MCA:
         self._analysis['is_rotated'] = False
         self._analysis['n_rot'] = len(singular_values)
         self._analysis['power'] = 0
-        self._rotation_matrix = np.eye(len(singular_values))
-        self._correlation_matrix = np.eye(len(singular_values))
+        # unrotated: both are the unit matrix (array.py:594-595) - built by rotation_matrix() / correlation_matrix() when
+        # somebody asks (two rank x rank arrays are 400 MB at rank 5000, and rotate() would pay for freeing them)
+        for name in ('_rotation_matrix', '_correlation_matrix'):
+            if hasattr(self, name):
+                delattr(self, name)
         self._analysis['is_truncated_at'] = len(singular_values)
 
     # ------------------------------------------------------------------------------------------
@@ -688,12 +691,20 @@ class MCA:
             raise ValueError('`n_rot` must be > 1')
         if power < 1:
             raise ValueError('`power` must be >=1')
-        sqrt_svals = np.sqrt(self._get_svals(n_rot))
-        V = self._get_V(n_rot, rotated=False)
-        n_vars_left = V['left'].shape[0]
-        # loadings of both fields stacked (Cheng and Dunkerton 1995)
-        L = np.concatenate(list(V.values())) * sqrt_svals
-        out = self._device().rotate_loadings(L, n_left=n_vars_left, power=power, tol=tol, max_iter=1000)
+        dev = self._device()
+        V = getattr(self, '_V', None)
+        if (isinstance(V, _LazyVectors) and V._pending == set(self._keys) and dev.holds_result_of(self)
+                and n_rot <= self._analysis['rank'] and V._dtype == np.float64):
+            # the vectors of solve() are still resident: the stacked loadings V sqrt(s) are built on the device
+            # (float32 models take the host path: the reference rotates the float32-rounded loadings)
+            out = dev.rotate_solved(n_rot, power=power, tol=tol, max_iter=1000)
+        else:
+            sqrt_svals = np.sqrt(self._get_svals(n_rot))
+            V = self._get_V(n_rot, rotated=False)
+            n_vars_left = V['left'].shape[0]
+            # loadings of both fields stacked (Cheng and Dunkerton 1995)
+            L = np.concatenate(list(V.values())) * sqrt_svals
+            out = dev.rotate_loadings(L, n_left=n_vars_left, power=power, tol=tol, max_iter=1000)
         self._varimax_iterations = out['n_iter']
 
         norm = {'left': out['norm_left'], 'right': out['norm_right']}

@@ -684,7 +684,36 @@ __device__ long long rot_prof[16];
 #define ROT_STAMP(k) do { } while (0)
 #endif
 
-static inline size_t rot_polar_smem(int p, bool cplx) { return sizeof(double) * ((cplx ? 2 : 1) * 4 * (size_t)p * p + 1024); }
+// Scaled Newton-Schulz step  X <- a X - b X (X^H X)  for singular values in [ell, 1]:  a = 3 rho / 2, b = rho^3 / 2 with
+// rho = sqrt(3 / (1 + ell + ell^2)) maps [ell, 1] onto [ell', 1], ell' = rho ell (3 - rho^2 ell^2) / 2, the largest ell' a cubic
+// of this form can reach (Chen & Chow 2014): small singular values grow by up to 2.6 per step instead of 1.5.  Safe for
+// any guess of ell - the polynomial stays within (0, 1] on (0, 1] - a guess too large only delays the values below it.
+// ell is advanced in place; rho = 1 (the plain iteration) once ell has reached 1.
+__device__ __forceinline__ void ns_scaled_coefficients(double& ell, double& a, double& b) {
+  if (ell < 1.0 - 1e-9) {
+    // (hardware reciprocal square root, ~1e-8: any rho <= sqrt(3) is admissible, and every workgroup computes the same one)
+    const double rs = __builtin_amdgcn_rsq(1.0 + ell + ell * ell);
+    const double rho = fmin(1.7320508075688772 * rs, 1.7320508075688772), rho2 = rho * rho;
+    a = 1.5 * rho;
+    b = 0.5 * rho * rho2;
+    ell = fmin(1.0, 0.5 * rho * ell * (3.0 - rho2 * ell * ell));
+  } else {
+    a = 1.5;
+    b = 0.5;
+    ell = 1.0;
+  }
+}
+
+// Newton-Schulz for 16 < p <= 32 keeps X, T and the next X zero-padded to 32 rows at pitch ROT_NSLD (no clamped or masked
+// operand, no bounds in the epilogues); the three buffers of a plane follow G and R and are time-shared with the tail's
+// two p x p work matrices.
+constexpr int ROT_NSLD = 34;
+constexpr int ROT_NSP = 32 * ROT_NSLD;
+__host__ __device__ static inline size_t rot_polar_plane(int p) {
+  const size_t pp = (size_t)p * p;
+  return (p > 16 && p <= 32) ? 2 * pp + 3 * (size_t)ROT_NSP : 4 * pp;
+}
+static inline size_t rot_polar_smem(int p, bool cplx) { return sizeof(double) * ((cplx ? 2 : 1) * rot_polar_plane(p) + 1024); }
 
 // Newton-Schulz for p <= 16 by ONE wave with everything in registers.  X (padded to 16 x 16) lives in the C/D layout
 // of v_mfma_f64_16x16x4_f64 (lane l, register r <-> entry [l/16 + 4r][l%16]), and so does its plain transpose Xt.
@@ -697,7 +726,7 @@ static inline size_t rot_polar_smem(int p, bool cplx) { return sizeof(double) * 
 // Returns the iteration count, or -1 (NaN / no convergence).  Call with one full wave; X goes to Xr/Xi (p x p).
 template <bool CPLX>
 __device__ __forceinline__ int varimax_ns_wave16(const double* __restrict__ Gr, const double* __restrict__ Gi, const int p,
-                                                 const double inv, double* __restrict__ Xr, double* __restrict__ Xi) {
+                                                 const double inv, double* __restrict__ Xr, double* __restrict__ Xi, double ell) {
   const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
   double xr[4], xtr[4], xi[4], xti[4];
   bool in[4];
@@ -741,13 +770,15 @@ __device__ __forceinline__ int varimax_ns_wave16(const double* __restrict__ Gr, 
       yti = S(tii, xtr, zero, 1.0);
       yti = S(trr, xti, yti, 1.0);
     }
+    double ca, cb;
+    ns_scaled_coefficients(ell, ca, cb);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      xr[r] = 1.5 * xr[r] - 0.5 * yr[r];
-      xtr[r] = 1.5 * xtr[r] - 0.5 * ytr[r];
+      xr[r] = ca * xr[r] - cb * yr[r];
+      xtr[r] = ca * xtr[r] - cb * ytr[r];
       if constexpr (CPLX) {
-        xi[r] = 1.5 * xi[r] - 0.5 * yi[r];
-        xti[r] = 1.5 * xti[r] - 0.5 * yti[r];
+        xi[r] = ca * xi[r] - cb * yi[r];
+        xti[r] = ca * xti[r] - cb * yti[r];
       }
     }
   }
@@ -784,9 +815,9 @@ __device__ __forceinline__ void ns_tile_unrolled(const double* __restrict__ Ar, 
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     acc_r = Mfma<double>::mma(ar[s], br[s], acc_r);
-    if constexpr (CPLX) {
-      acc_r = Mfma<double>::mma(TSTEP ? ai[s] : -ai[s], bi[s], acc_r);   // T: conj(a) b;  Y: a b
+    if constexpr (CPLX) {                                                  // (the two chains alternate: no MFMA waits for its predecessor)
       acc_i = Mfma<double>::mma(ar[s], bi[s], acc_i);
+      acc_r = Mfma<double>::mma(TSTEP ? ai[s] : -ai[s], bi[s], acc_r);   // T: conj(a) b;  Y: a b
       acc_i = Mfma<double>::mma(TSTEP ? -ai[s] : ai[s], br[s], acc_i);
     }
   }
@@ -806,6 +837,135 @@ __device__ __forceinline__ void ns_tile(const int ksteps, const double* __restri
 #undef XMCA_NS_CASE
 }
 
+// Newton-Schulz for 16 < p <= 32: one 16 x 16 tile of T = X^H X and of Y = X T per wave, KS = ceil(p / 4) summation steps,
+// every LDS offset computed once before the loop.  P0 / P1 / PT: the padded buffers (real planes; imaginary at + plane).
+// Leaves the polar factor in (Xr, Xi) at pitch p.  Returns the iteration count, -1 on NaN / no convergence.
+template <bool CPLX, int KS>
+__device__ __forceinline__ int varimax_ns_pt2(const double* __restrict__ Gr, const double* __restrict__ Gi, const int p, const double inv,
+                                              double* __restrict__ Xr, double* __restrict__ Xi, double* __restrict__ padr,
+                                              double* __restrict__ padi, int* __restrict__ nsflag, double ell) {
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4, wv = tid >> 6;
+  const int ti = wv >> 1, tj = wv & 1;
+  double* Cr = padr;                 // current X
+  double* Ci = padi;
+  double* Nr = padr + ROT_NSP;       // next X
+  double* Ni = padi + ROT_NSP;
+  double* Tr = padr + 2 * ROT_NSP;
+  double* Ti = padi + 2 * ROT_NSP;
+  for (int idx = tid; idx < ROT_NSP; idx += 256) {
+    const int row = idx / ROT_NSLD, col = idx - row * ROT_NSLD;
+    const bool in = row < p && col < p;
+    const int g = in ? row * p + col : 0;
+    const double vr = Gr[g], vi = CPLX ? Gi[g] : 0.0;
+    Cr[idx] = in ? vr * inv : 0.0;
+    if constexpr (CPLX) Ci[idx] = in ? vi * inv : 0.0;
+  }
+  const int oa_t = l4 * ROT_NSLD + 16 * ti + l15;        // T step: a = X[k][16 ti + i], b = X[k][16 tj + j], k = l4 + 4 s
+  const int ob = l4 * ROT_NSLD + 16 * tj + l15;          //         (and the b operand T[k][16 tj + j] of the Y step)
+  const int oa_y = (16 * ti + l15) * ROT_NSLD + l4;      // Y step: a = X[16 ti + i][k]
+  const int oo = (16 * ti + l4) * ROT_NSLD + 16 * tj + l15;   // this lane's four entries of the tile: rows + 4 r
+  double tgt[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 16 * ti + l4 + 4 * r, col = 16 * tj + l15;
+    tgt[r] = (row == col && row < p) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  int it = 0;
+  bool ok = false;
+  for (; it < 100; ++it) {
+    if (it == 1) ROT_STAMP(8);
+    {
+      double ar[KS], ai[KS], br[KS], bi[KS];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        ar[s] = Cr[oa_t + 4 * s * ROT_NSLD];
+        br[s] = Cr[ob + 4 * s * ROT_NSLD];
+        if constexpr (CPLX) {
+          ai[s] = Ci[oa_t + 4 * s * ROT_NSLD];
+          bi[s] = Ci[ob + 4 * s * ROT_NSLD];
+        }
+      }
+      d4_t tr = {0, 0, 0, 0}, tim = {0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        tr = Mfma<double>::mma(ar[s], br[s], tr);
+        if constexpr (CPLX) {                         // conj(a) b
+          tim = Mfma<double>::mma(ar[s], bi[s], tim);
+          tr = Mfma<double>::mma(ai[s], bi[s], tr);
+          tim = Mfma<double>::mma(-ai[s], br[s], tim);
+        }
+      }
+      if (it == 1) ROT_STAMP(14);
+      bool open = false, nan = false;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        Tr[oo + 4 * r * ROT_NSLD] = tr[r];
+        if constexpr (CPLX) Ti[oo + 4 * r * ROT_NSLD] = tim[r];
+        const double err = fmax(fabs(tr[r] - tgt[r]), fabs(tim[r]));
+        open |= !(err < 1e-14);
+        nan |= !(err == err) || err == HUGE_VAL;
+      }
+      if (open) nsflag[it & 1] = 1;
+      if (nan) nsflag[2] = 1;
+    }
+    if (tid == 0) nsflag[(it + 1) & 1] = 0;   // next iteration's flag (its last reader passed the previous barrier)
+    if (it == 1) ROT_STAMP(9);
+    __syncthreads();
+    if (it == 1) ROT_STAMP(10);
+    if (nsflag[2]) break;                       // NaN / inf
+    if (!nsflag[it & 1]) { ok = true; break; }
+    if (it == 1) ROT_STAMP(11);
+    double coef_a, coef_b;
+    ns_scaled_coefficients(ell, coef_a, coef_b);
+    {
+      double ar[KS], ai[KS], br[KS], bi[KS], xr[4], xi[4];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        ar[s] = Cr[oa_y + 4 * s];
+        br[s] = Tr[ob + 4 * s * ROT_NSLD];
+        if constexpr (CPLX) {
+          ai[s] = Ci[oa_y + 4 * s];
+          bi[s] = Ti[ob + 4 * s * ROT_NSLD];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        xr[r] = Cr[oo + 4 * r * ROT_NSLD];
+        xi[r] = CPLX ? Ci[oo + 4 * r * ROT_NSLD] : 0.0;
+      }
+      d4_t yr = {0, 0, 0, 0}, yi = {0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        yr = Mfma<double>::mma(ar[s], br[s], yr);
+        if constexpr (CPLX) {                         // a b
+          yi = Mfma<double>::mma(ar[s], bi[s], yi);
+          yr = Mfma<double>::mma(-ai[s], bi[s], yr);
+          yi = Mfma<double>::mma(ai[s], br[s], yi);
+        }
+      }
+      if (it == 1) ROT_STAMP(15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        Nr[oo + 4 * r * ROT_NSLD] = coef_a * xr[r] - coef_b * yr[r];
+        if constexpr (CPLX) Ni[oo + 4 * r * ROT_NSLD] = coef_a * xi[r] - coef_b * yi[r];
+      }
+    }
+    if (it == 1) ROT_STAMP(12);
+    __syncthreads();
+    if (it == 1) ROT_STAMP(13);
+    { double* t = Cr; Cr = Nr; Nr = t; }
+    { double* t = Ci; Ci = Ni; Ni = t; }
+  }
+  for (int e = tid; e < p * p; e += 256) {      // the tail works at pitch p
+    const int row = e / p, col = e - row * p;
+    Xr[e] = Cr[row * ROT_NSLD + col];
+    if constexpr (CPLX) Xi[e] = Ci[row * ROT_NSLD + col];
+  }
+  __syncthreads();
+  return ok ? it : -1;
+}
+
 template <bool CPLX>
 __device__ __forceinline__ void varimax_polar_step(double* __restrict__ sm, const double* __restrict__ part_r, const double* __restrict__ part_i,
                                    int nwg, int p, const double* __restrict__ A0r, const double* __restrict__ A0i,
@@ -814,9 +974,9 @@ __device__ __forceinline__ void varimax_polar_step(double* __restrict__ sm, cons
   const int tid = threadIdx.x, pp = p * p;
   double* Gr = sm;            // G, later A0 R
   double* Xr = Gr + pp;
-  double* Tr = Xr + pp;
+  double* Tr = Xr + pp;       // (16 < p <= 32: T and Y share their space with the padded buffers of varimax_ns_pt2)
   double* Yr = Tr + pp;
-  double* scr = Yr + pp;      // 1024 doubles of scratch
+  double* scr = sm + rot_polar_plane(p);      // 1024 doubles of scratch
   double* Gi = scr + 1024;
   double* Xi = Gi + pp;
   double* Ti = Xi + pp;
@@ -904,6 +1064,10 @@ __device__ __forceinline__ void varimax_polar_step(double* __restrict__ sm, cons
   // (j, k) of a thread's first entry is computed once (a 32-bit division per matmul is as long as the matmul).
   int it = 0;
   bool ok = false;
+  // lower bound guess for the singular values of X0 = G / ||G||_F: half the smallest diagonal entry of H = R^H G of the
+  // previous Varimax iteration (state[6], written by the tail below; H changes slowly), 1e-3 at the start
+  const double ell0 = (state[6] > 1e-6 && state[6] < 1.0) ? state[6] : 1e-3;
+  double ell = ell0;
   double* Cr = Xr;   // current iterate
   double* Ci = Xi;
   double* Nr = Yr;   // next iterate
@@ -915,7 +1079,7 @@ __device__ __forceinline__ void varimax_polar_step(double* __restrict__ sm, cons
   if (p <= 16) {
     // register-resident MFMA form; it restarts from G (the scaled copy in X is not needed)
     if (tid < 64) {
-      const int n_it = varimax_ns_wave16<CPLX>(Gr, Gi, p, inv, Xr, Xi);
+      const int n_it = varimax_ns_wave16<CPLX>(Gr, Gi, p, inv, Xr, Xi, ell0);
       if (tid == 0) nsflag[3] = n_it;
     }
     __syncthreads();
@@ -923,7 +1087,19 @@ __device__ __forceinline__ void varimax_polar_step(double* __restrict__ sm, cons
     ok = it >= 0;
     if (!ok) it = 100;
   }
-  // p > 16: the two products of an iteration as 16 x 16 MFMA tiles (v_mfma_f64_16x16x4_f64), the PT x PT output tiles
+  if (p > 16 && p <= 32) {
+    __syncthreads();            // (X0 at pitch p, written above, is not used by this form: it starts from G)
+    int n_it;
+    switch ((p + 3) >> 2) {
+      case 5: n_it = varimax_ns_pt2<CPLX, 5>(Gr, Gi, p, inv, Xr, Xi, Tr, Ti, nsflag, ell0); break;
+      case 6: n_it = varimax_ns_pt2<CPLX, 6>(Gr, Gi, p, inv, Xr, Xi, Tr, Ti, nsflag, ell0); break;
+      case 7: n_it = varimax_ns_pt2<CPLX, 7>(Gr, Gi, p, inv, Xr, Xi, Tr, Ti, nsflag, ell0); break;
+      default: n_it = varimax_ns_pt2<CPLX, 8>(Gr, Gi, p, inv, Xr, Xi, Tr, Ti, nsflag, ell0); break;
+    }
+    ok = n_it >= 0;
+    it = ok ? n_it : 100;
+  }
+  // p > 32: the two products of an iteration as 16 x 16 MFMA tiles (v_mfma_f64_16x16x4_f64), the PT x PT output tiles
   // dealt round-robin to the four waves; operands straight from LDS (X and T at pitch p).  Rows / columns beyond p are
   // read from a clamped address - an operand row (column) only reaches the same row (column) of the product, which is
   // not stored - and the summation index beyond p (last step only) is masked with a factor 0: no branch around any load.
@@ -933,7 +1109,7 @@ __device__ __forceinline__ void varimax_polar_step(double* __restrict__ sm, cons
   const int PT = (p + 15) >> 4, ksteps = (p + 3) >> 2;
   const int klast = min(4 * (ksteps - 1) + l4, p - 1);                    // summation index of the last step, clamped ...
   const double kmask = 4 * (ksteps - 1) + l4 < p ? 1.0 : 0.0;             // ... and masked
-  for (; p > 16 && it < 100; ++it) {
+  for (; p > 32 && it < 100; ++it) {
     if (it == 1) ROT_STAMP(8);
     for (int t = wv; t < PT * PT; t += 4) {
       const int ia = 16 * (t / PT) + l15, jb = 16 * (t % PT) + l15, ca = min(ia, p - 1), cb = min(jb, p - 1);
@@ -962,6 +1138,8 @@ __device__ __forceinline__ void varimax_polar_step(double* __restrict__ sm, cons
     if (nsflag[2]) break;                       // NaN / inf
     if (!nsflag[it & 1]) { ok = true; break; }
     if (it == 1) ROT_STAMP(11);
+    double coef_a, coef_b;
+    ns_scaled_coefficients(ell, coef_a, coef_b);
     for (int t = wv; t < PT * PT; t += 4) {
       const int ia = 16 * (t / PT) + l15, jb = 16 * (t % PT) + l15, ca = min(ia, p - 1), cb = min(jb, p - 1);
       d4_t yr = {0, 0, 0, 0}, yi = {0, 0, 0, 0};
@@ -971,8 +1149,8 @@ __device__ __forceinline__ void varimax_polar_step(double* __restrict__ sm, cons
       for (int r = 0; r < 4; ++r) {
         const int row = 16 * (t / PT) + l4 + 4 * r;
         if (row < p && jb < p) {
-          Nr[row * p + jb] = 1.5 * Cr[row * p + jb] - 0.5 * yr[r];
-          if constexpr (CPLX) Ni[row * p + jb] = 1.5 * Ci[row * p + jb] - 0.5 * yi[r];
+          Nr[row * p + jb] = coef_a * Cr[row * p + jb] - coef_b * yr[r];
+          if constexpr (CPLX) Ni[row * p + jb] = coef_a * Ci[row * p + jb] - coef_b * yi[r];
         }
       }
     }
@@ -1000,8 +1178,42 @@ __device__ __forceinline__ void varimax_polar_step(double* __restrict__ sm, cons
     Tr[e] = A0r[e];
     if constexpr (CPLX) { Ri[e] = Xi[e]; Ti[e] = A0i[e]; }
   }
+  if (tid < 4 * p) {                              // H_kk = Re sum_j conj(R[j][k]) G[j][k], four threads per column
+    const int k = tid >> 2;
+    double hk = 0.0;
+    for (int j = tid & 3; j < p; j += 4) {
+      hk += Xr[j * p + k] * Gr[j * p + k];
+      if constexpr (CPLX) hk += Xi[j * p + k] * Gi[j * p + k];
+    }
+    hk += __shfl_xor(hk, 1);
+    hk += __shfl_xor(hk, 2);
+    if ((tid & 3) == 0) scr[512 + k] = hk;
+  }
   dsum = block_reduce(dsum, false);
-  for (int e = tid; e < pp; e += 256) {
+  if (tid == 0) {
+    double hmin = scr[512];
+    for (int k = 1; k < p; ++k) hmin = fmin(hmin, scr[512 + k]);
+    state[6] = 0.5 * hmin * inv;                  // next iteration's guess (ignored unless within (1e-6, 1))
+  }
+  if (p > 16) {
+    // prod = Re conj(R) . (A0 R), the product as MFMA tiles like the Newton-Schulz Y step (operands: A0 staged in T, R in X)
+    __syncthreads();
+    for (int t = wv; t < PT * PT; t += 4) {
+      const int ia = 16 * (t / PT) + l15, jb = 16 * (t % PT) + l15, ca = min(ia, p - 1), cb = min(jb, p - 1);
+      d4_t yr = {0, 0, 0, 0}, yi = {0, 0, 0, 0};
+      ns_tile<CPLX, false>(ksteps, Tr, Ti, Xr, Xi, ca * p + l4, 4, l4 * p + cb, 4 * p, ca * p + klast, klast * p + cb, kmask, yr, yi);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * (t / PT) + l4 + 4 * r;
+        if (row < p && jb < p) {
+          double prod = Xr[row * p + jb] * yr[r];
+          if constexpr (CPLX) prod += Xi[row * p + jb] * yi[r];
+          Yr[row * p + jb] = prod;
+        }
+      }
+    }
+  }
+  for (int e = tid; p <= 16 && e < pp; e += 256) {
     const int j = e / p, k = e % p;
     double tr = 0.0, ti = 0.0;
 #pragma unroll 5
@@ -1076,6 +1288,152 @@ __global__ __launch_bounds__(256) void varimax_iter_kernel(const double* __restr
   varimax_polar_step<CPLX>(sm, part_r, part_i, (int)gridDim.x, p, A0r, A0i, Rr, Ri, cvec, state, tol);
 }
 
+// The accumulation below for 16 < p <= 32 (two mode tiles per dimension) with every loop unrolled: KS = ceil(p / 4) summation
+// steps in the Z products.  R's MFMA operands are loaded once per iteration instead of once per tile and product, all LDS
+// operands of a stage are requested before its first MFMA, and the four accumulator chains of a stage alternate (the
+// run-time loops of the general form wait for every LDS operand and every dependent MFMA in turn: 180 cycles per MFMA
+// against 64 of issue - C3's 20 complex modes: 93k cycles per iteration in this stage).  One G tile per wave.
+template <bool CPLX, int KS>
+__device__ __forceinline__ void varimax_accum_mfma_pt2(double* __restrict__ sm, const double* __restrict__ Ar,
+                                                       const double* __restrict__ Ai, const int64_t N, const int p,
+                                                       const double* __restrict__ Rr, const double* __restrict__ Ri,
+                                                       const double* __restrict__ cvec, double* __restrict__ out_r,
+                                                       double* __restrict__ out_i, double* __restrict__ res_r,
+                                                       double* __restrict__ res_i, const bool res_ready, const double gamma) {
+  const int pl = p * ROT_LDP, pp = p * p;
+  double* Xr = sm;
+  double* Yr = Xr + pl;
+  double* Xi = Yr + pl + pp + ROT_PB;     // (the layout of varimax_accum_mfma: Xs, tile, R copy, weights per plane)
+  double* Yi = Xi + pl;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+  // B operands of Z = A R:  R[4 s + l4][16 kt + l15], zero outside p x p
+  double rbr[2][KS], rbi[2][KS];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int j = 4 * s + l4, k = 16 * kt + l15;
+      const bool in = j < p && k < p;
+      const int idx = in ? j * p + k : 0;
+      const double vr = Rr[idx], vi = CPLX ? Ri[idx] : 0.0;
+      rbr[kt][s] = in ? vr : 0.0;
+      rbi[kt][s] = in ? vi : 0.0;
+    }
+  }
+  double cn[2];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt) {
+    const int k = 16 * kt + l15;
+    cn[kt] = k < p ? gamma * (cvec[k] / (double)N) : 0.0;
+  }
+  // this wave's tile of G
+  const int gjt = wave >> 1, gkt = wave & 1;
+  const int gj = 16 * gjt + l15, gk = 16 * gkt + l15;
+  const bool gjin = gj < p, gkin = gk < p;
+  const int gja = (gjin ? gj : 0) * ROT_LDP + l4, gka = (gkin ? gk : 0) * ROT_LDP + l4;
+  d4_t gr = {0, 0, 0, 0}, gi = {0, 0, 0, 0};
+
+  const int64_t nbatch = (N + ROT_PB - 1) / ROT_PB;
+  for (int64_t bt = blockIdx.x; bt < nbatch; bt += gridDim.x) {
+    const int64_t n0 = bt * ROT_PB;
+    double* Tr = Yr;
+    double* Ti = Yi;
+    if (res_r) {
+      const int64_t bl = (bt - blockIdx.x) / gridDim.x;
+      Tr = res_r + bl * pl;
+      Ti = res_i + bl * pl;
+    }
+    __syncthreads();                      // the previous tile's W is no longer read
+    if (!res_r || !res_ready) {
+      for (int e = tid; e < p * ROT_PB; e += 256) {
+        const int j = e / ROT_PB, pt = e % ROT_PB;
+        const int64_t n = n0 + pt;
+        double vr = 0.0, vi = 0.0;
+        if (n < N) {
+          vr = Ar[(int64_t)j * N + n];
+          if constexpr (CPLX) vi = Ai[(int64_t)j * N + n];
+        }
+        Tr[j * ROT_LDP + pt] = vr;
+        if constexpr (CPLX) Ti[j * ROT_LDP + pt] = vi;
+      }
+      __syncthreads();
+    }
+    // ---- Z rows of this wave's 16 points, both mode tiles at once ----
+    double ar[KS], ai[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int j = 4 * s + l4;
+      const bool jin = j < p;
+      const int a = (jin ? j : 0) * ROT_LDP + wave * 16 + l15;
+      const double vr = Tr[a], vi = CPLX ? Ti[a] : 0.0;
+      ar[s] = jin ? vr : 0.0;
+      ai[s] = jin ? vi : 0.0;
+    }
+    d4_t zr[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, zi[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      zr[0] = Mfma<double>::mma(ar[s], rbr[0][s], zr[0]);
+      zr[1] = Mfma<double>::mma(ar[s], rbr[1][s], zr[1]);
+      if constexpr (CPLX) {
+        zi[0] = Mfma<double>::mma(ar[s], rbi[0][s], zi[0]);
+        zi[1] = Mfma<double>::mma(ar[s], rbi[1][s], zi[1]);
+        zr[0] = Mfma<double>::mma(-ai[s], rbi[0][s], zr[0]);
+        zr[1] = Mfma<double>::mma(-ai[s], rbi[1][s], zr[1]);
+        zi[0] = Mfma<double>::mma(ai[s], rbr[0][s], zi[0]);
+        zi[1] = Mfma<double>::mma(ai[s], rbr[1][s], zi[1]);
+      }
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      const int k = 16 * kt + l15;
+      if (k < p) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          // W = (|z|^2 - c_k / N) z     (rotation.py:56-57)
+          const double f = zr[kt][r] * zr[kt][r] + zi[kt][r] * zi[kt][r] - cn[kt];
+          const int pt = wave * 16 + l4 + 4 * r;
+          Xr[k * ROT_LDP + pt] = f * zr[kt][r];
+          if constexpr (CPLX) Xi[k * ROT_LDP + pt] = f * zi[kt][r];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- G[j][k] += sum_pt conj(A[pt][j]) W[pt][k]: 16 steps of four points, eight steps' operands in flight ----
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      double qa[8], qb[8], wa[8], wb[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int o = 4 * (8 * half + u);
+        const double va = Tr[gja + o], vw = Xr[gka + o];
+        const double vb = CPLX ? Ti[gja + o] : 0.0, vx = CPLX ? Xi[gka + o] : 0.0;
+        qa[u] = gjin ? va : 0.0;
+        qb[u] = gjin ? vb : 0.0;
+        wa[u] = gkin ? vw : 0.0;
+        wb[u] = gkin ? vx : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        gr = Mfma<double>::mma(qa[u], wa[u], gr);
+        if constexpr (CPLX) {
+          gi = Mfma<double>::mma(qa[u], wb[u], gi);
+          gr = Mfma<double>::mma(qb[u], wb[u], gr);      // conj(a) w
+          gi = Mfma<double>::mma(-qb[u], wa[u], gi);
+        }
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int j = 16 * gjt + l4 + 4 * r, k = 16 * gkt + l15;
+    if (j < p && k < p) {
+      out_r[j * p + k] = gr[r];
+      if constexpr (CPLX) out_i[j * p + k] = gi[r];
+    }
+  }
+}
+
 // MFMA form of the Varimax accumulation (MODE 0 of rot_accum_body) for the persistent kernel:
 //   Z = A R (64 grid points x p per tile),  W = (|Z|^2 - c/N) Z,  G += A^H W
 // as v_mfma_f64_16x16x4_f64 products on 16-wide mode tiles (PT = ceil(p/16) per dimension).  Wave w computes the Z rows
@@ -1099,6 +1457,14 @@ __device__ __forceinline__ void varimax_accum_mfma(double* __restrict__ sm, cons
   double* Rsi = Yi + pl;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
   const int PT = (p + 15) / 16;
+  if (PT == 2) {
+    switch ((p + 3) >> 2) {
+      case 5: varimax_accum_mfma_pt2<CPLX, 5>(sm, Ar, Ai, N, p, Rr, Ri, cvec, out_r, out_i, res_r, res_i, res_ready, gamma); return;
+      case 6: varimax_accum_mfma_pt2<CPLX, 6>(sm, Ar, Ai, N, p, Rr, Ri, cvec, out_r, out_i, res_r, res_i, res_ready, gamma); return;
+      case 7: varimax_accum_mfma_pt2<CPLX, 7>(sm, Ar, Ai, N, p, Rr, Ri, cvec, out_r, out_i, res_r, res_i, res_ready, gamma); return;
+      default: varimax_accum_mfma_pt2<CPLX, 8>(sm, Ar, Ai, N, p, Rr, Ri, cvec, out_r, out_i, res_r, res_i, res_ready, gamma); return;
+    }
+  }
   constexpr int MAXT = 4;                 // G tiles per wave: ceil(PT^2 / 4) <= 4
   for (int e = tid; e < pp; e += 256) {
     Rsr[e] = Rr[e];
@@ -1262,7 +1628,7 @@ __global__ __launch_bounds__(256) void varimax_persistent_kernel(const double* _
                                                                  const double* __restrict__ A0r, const double* __restrict__ A0i,
                                                                  double* Rr, double* Ri, double* cvec, double* state, double* part_r,
                                                                  double* part_i, unsigned int* flags, double tol, int max_iter,
-                                                                 size_t work_doubles, int resident_tiles, double gamma, int poll_delay) {
+                                                                 size_t work_doubles, int resident_tiles, double gamma, int poll_delay, double* sums) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* sm = reinterpret_cast<double*>(smem_raw);          // accumulate / polar scratch (time-shared)
   const int pp = p * p, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1306,27 +1672,85 @@ __global__ __launch_bounds__(256) void varimax_persistent_kernel(const double* _
     __syncthreads();
     if (tid == 0) __hip_atomic_store(flags + bid, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ROT_STAMP(6);
-    if (wave == 0) {
-      // (the first poll waits: polling while the others still publish slows them down - measured on the tridiagonal
-      //  reduction's exchange, csrc/tridiag.h)
-      if (poll_delay >= 16) __builtin_amdgcn_s_sleep(16);
-      else if (poll_delay >= 8) __builtin_amdgcn_s_sleep(8);
-      else if (poll_delay >= 4) __builtin_amdgcn_s_sleep(4);
-      unsigned int spins = 0;
-      for (;;) {
-        bool ok = true;
-        for (int w = lane; w < nwg; w += 64) ok &= __hip_atomic_load(flags + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch;
-        if (__all(ok)) break;
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1u << 22)) { if (lane == 0) give_up = 1; break; }   // a workgroup is missing: report, never hang
+    // Two-stage reduction (sums != nullptr): entry e of G is added up - over the workgroups in a fixed order - by workgroup
+    // e / chunk alone, which publishes the sums under a second flag; everybody then reads one p x p matrix.  The all-to-all
+    // form (every workgroup reads every partial: nwg x p^2 doubles each, 34k cycles for C3's 110 x 800) remains for grids
+    // too small to split the entries.
+    constexpr int PLANES = CPLX ? 2 : 1;
+    const int chunk = (pp + nwg - 1) / nwg;                    // entries per reducing workgroup
+    const int nred = (pp + chunk - 1) / chunk;                 // workgroups that reduce
+    const bool two_stage = sums != nullptr && chunk * PLANES <= 64 && nwg >= 16;
+    auto wait_flags = [&](const unsigned int* f, int count) {
+      if (wave == 0) {
+        // (the first poll waits: polling while the others still publish slows them down - measured on the tridiagonal
+        //  reduction's exchange, csrc/tridiag.h)
+        if (poll_delay >= 16) __builtin_amdgcn_s_sleep(16);
+        else if (poll_delay >= 8) __builtin_amdgcn_s_sleep(8);
+        else if (poll_delay >= 4) __builtin_amdgcn_s_sleep(4);
+        unsigned int spins = 0;
+        for (;;) {
+          bool ok = true;
+          for (int w = lane; w < count; w += 64) ok &= __hip_atomic_load(f + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch;
+          if (__all(ok)) break;
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > (1u << 22)) { if (lane == 0) give_up = 1; break; }   // a workgroup is missing: report, never hang
+        }
+        if (lane == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       }
+      __syncthreads();
+    };
+    const double* red_r = pub_r;
+    const double* red_i = pub_i;
+    int red_n = nwg;
+    if (two_stage) {
+      double* sum_r = sums + (size_t)(it & 1) * 2 * pp;
+      double* sum_i = sum_r + pp;
+      if (bid < nred) {
+        wait_flags(flags, nwg);
+        ROT_STAMP(7);
+        if (!give_up) {
+          // column = (entry of my chunk, plane); slice sl adds the workgroups sl, sl + nsl, ... (8 loads in flight), the slices
+          // are then added in order: one fixed summation order per entry
+          const int e0 = bid * chunk, ne = min(chunk, pp - e0), cols = ne * PLANES, nsl = 256 / cols;
+          const int col = tid % cols, sl = tid / cols;
+          if (sl < nsl) {
+            const double* src = (CPLX && col >= ne) ? pub_i + e0 + (col - ne) : pub_r + e0 + col;
+            double acc = 0.0;
+            for (int w0 = sl; w0 < nwg; w0 += 8 * nsl) {
+              double v[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                const int ww = w0 + u * nsl;
+                v[u] = ww < nwg ? __hip_atomic_load(src + (size_t)ww * pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+              }
+#pragma unroll
+              for (int u = 0; u < 8; ++u) acc += v[u];
+            }
+            sm[sl * cols + col] = acc;
+          }
+          __syncthreads();
+          if (tid < cols) {
+            double tot = 0.0;
+            for (int q = 0; q < nsl; ++q) tot += sm[q * cols + tid];
+            double* dst = (CPLX && tid >= ne) ? sum_i + e0 + (tid - ne) : sum_r + e0 + tid;
+            __hip_atomic_store(dst, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          if (tid == 0) __hip_atomic_store(flags + nwg + bid, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      if (!give_up) wait_flags(flags + nwg, nred);
+      red_r = sum_r;
+      red_i = sum_i;
+      red_n = 1;
+    } else {
+      wait_flags(flags, nwg);
       ROT_STAMP(7);
-      if (lane == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
-    __syncthreads();
     if (give_up) { if (tid == 0) stl[4] = 2.0; __syncthreads(); break; }
     ROT_STAMP(2);
-    varimax_polar_step<CPLX>(sm, pub_r, pub_i, nwg, p, a0_r, a0_i, Rl_r, Rl_i, cl, stl, tol);
+    varimax_polar_step<CPLX>(sm, red_r, red_i, red_n, p, a0_r, a0_i, Rl_r, Rl_i, cl, stl, tol);
     __syncthreads();
   }
   if (bid == 0) {

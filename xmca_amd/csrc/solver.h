@@ -1270,9 +1270,14 @@ class Rotator {
   Rotator(hipStream_t s, StageTimer& t, GemmWorkspace& g, EvdWorkspace& e) : st(s), tm(t), gws(&g), ews(&e) {}
   static bool fused_fits(int p, bool cplx) { return p <= rot_max_modes(cplx); }
 
-  static int pick_nwg(int64_t N) {
+  // `wide`: many modes (p^2 x planes >= 512 doubles per partial) - the accumulation dominates an iteration and the partials are
+  // summed in two stages whose cost does not grow with the grid (varimax_persistent_kernel): up to one workgroup per CU.
+  // Few modes: the all-to-all reduction and the exchange dominate - flat between 40 and 128 workgroups, slower beyond.
+  static bool wide_grid(int p, bool cplx) { return (size_t)p * p * (cplx ? 2 : 1) >= 512; }
+  static int pick_nwg(int64_t N, bool wide = false) {
     const int64_t nb = (N + ROT_PB - 1) / ROT_PB;
-    static const int cap = [] { const char* e = std::getenv("XMCA_ROT_WGS"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 128; }();
+    static const int cap_env = [] { const char* e = std::getenv("XMCA_ROT_WGS"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 0; }();
+    const int cap = cap_env > 0 ? cap_env : (wide ? 256 : 128);
     // equal shares: with 157 tiles and a cap of 128 workgroups, 79 workgroups of 2 tiles beat 128 of 1-2
     const int64_t per = (nb + cap - 1) / cap;
     return (int)std::max<int64_t>(1, (nb + per - 1) / per);
@@ -1299,7 +1304,7 @@ class Rotator {
     XMCA_CHECK(fused_fits(p, cplx) || (gws && ews), XMCA_ERR_UNSUPPORTED,
                "rotate: n_rot = " + std::to_string(p) + " needs the GEMM-based path (no workspace given)");
     d.N = N; d.Nleft = Nleft; d.p = p; d.cplx = cplx;
-    d.nwg = pick_nwg(N);
+    d.nwg = pick_nwg(N, wide_grid(p, cplx));
     d.A.ensure((size_t)p * N, cplx);
     d.h.ensure((size_t)N);
     d.R.ensure((size_t)p * p, cplx);
@@ -1340,8 +1345,8 @@ class Rotator {
     static const bool persist_on = [] { const char* e = std::getenv("XMCA_VARIMAX_PERSIST"); return !(e && e[0] == '0'); }();
     const size_t work_bytes = std::max(rot_accum_smem(p, CPLX), rot_polar_smem(p, CPLX));
     size_t persist_smem = rot_persistent_smem(p, CPLX);
-    const int tiles_per_wg = (int)(((d.N + ROT_PB - 1) / ROT_PB + d.nwg - 1) / d.nwg);
-    const bool resident = persist_smem + rot_resident_smem(p, CPLX, tiles_per_wg) <= 160 * 1024;
+    int tiles_per_wg = (int)(((d.N + ROT_PB - 1) / ROT_PB + d.nwg - 1) / d.nwg);
+    bool resident = persist_smem + rot_resident_smem(p, CPLX, tiles_per_wg) <= 160 * 1024;
     if (resident) persist_smem += rot_resident_smem(p, CPLX, tiles_per_wg);
     // the epoch exchange spins on every workgroup of the grid: all of them must be co-resident, one per CU (a
     // partitioned / CU-masked device has fewer CUs than the 128-workgroup cap -> per-iteration launches instead)
@@ -1359,6 +1364,19 @@ class Rotator {
       if (persist_inflight.fetch_add(d.nwg) + d.nwg > n_cus) {
         persist_inflight.fetch_sub(d.nwg);
         persist_ok = false;
+        // a wide grid next to another lane's: try again with the narrow one (the buffers are large enough for either)
+        const int narrow = pick_nwg(d.N, false);
+        const int tiles_narrow = (int)(((d.N + ROT_PB - 1) / ROT_PB + narrow - 1) / narrow);
+        if (narrow < d.nwg && persist_inflight.fetch_add(narrow) + narrow <= n_cus) {
+          d.nwg = narrow;
+          persist_ok = true;
+          persist_smem = rot_persistent_smem(p, CPLX);
+          resident = persist_smem + rot_resident_smem(p, CPLX, tiles_narrow) <= 160 * 1024;
+          tiles_per_wg = tiles_narrow;
+          if (resident) persist_smem += rot_resident_smem(p, CPLX, tiles_per_wg);
+        } else if (narrow < d.nwg) {
+          persist_inflight.fetch_sub(narrow);
+        }
       }
     }
     struct InflightGuard {
@@ -1370,17 +1388,20 @@ class Rotator {
       // missing there, and the per-iteration launches take over - the hand-over must not change R or the stop iteration
       const char* tg = std::getenv("XMCA_VARIMAX_TEST_GIVEUP");
       const int persist_iters = (tg && std::atoi(tg) > 0) ? std::min(std::atoi(tg), max_iter) : max_iter;
-      d.pflags.ensure((size_t)d.nwg);
-      d.ppart_r.ensure((size_t)2 * d.nwg * p * p);
+      d.pflags.ensure((size_t)2 * d.nwg);                        // partial published / chunk of the sum published
+      d.ppart_r.ensure((size_t)2 * d.nwg * p * p + 4 * (size_t)p * p);   // ... + the summed G (two parities, two planes)
       if (CPLX) d.ppart_i.ensure((size_t)2 * d.nwg * p * p);
-      XMCA_HIP(hipMemsetAsync(d.pflags.get(), 0, sizeof(unsigned int) * d.nwg, st));
+      XMCA_HIP(hipMemsetAsync(d.pflags.get(), 0, sizeof(unsigned int) * 2 * d.nwg, st));
+      // two-stage sum of the partials when every workgroup would otherwise read more than ~32k doubles (XMCA_ROT_TWO_STAGE=0 / 1 forces)
+      const bool rot_two_stage = [&] { const char* e = std::getenv("XMCA_ROT_TWO_STAGE"); return e ? e[0] != '0' : (size_t)d.nwg * p * p * (CPLX ? 2 : 1) > 32768; }();
       const int rot_poll_delay = [] { const char* e = std::getenv("XMCA_ROT_POLL_DELAY"); return e ? std::atoi(e) : 0; }();   // (no measurable effect here: 0)
       XMCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(varimax_persistent_kernel<CPLX>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_smem));
       hipLaunchKernelGGL((varimax_persistent_kernel<CPLX>), dim3(d.nwg), dim3(256), persist_smem, st, d.A.r(), d.A.i(CPLX), d.h.get(),
                          d.N, p, d.A0.r(), d.A0.i(CPLX), d.R.r(), d.R.i(CPLX), d.cvec.get(), d.state.get(), d.ppart_r.get(),
                          CPLX ? d.ppart_i.get() : nullptr, d.pflags.get(), tol, persist_iters, work_bytes / sizeof(double),
-                         resident ? tiles_per_wg : 0, gamma, rot_poll_delay);
+                         resident ? tiles_per_wg : 0, gamma, rot_poll_delay,
+                         rot_two_stage ? d.ppart_r.get() + (size_t)2 * d.nwg * p * p : nullptr);
       XMCA_HIP(hipGetLastError());
       XMCA_HIP(hipMemcpyAsync(state, d.state.get(), sizeof(state), hipMemcpyDeviceToHost, st));
       XMCA_HIP(hipStreamSynchronize(st));

@@ -785,6 +785,7 @@ int xmca_solve(xmca_handle* h, int n_fields, int64_t n_vec, int64_t* rank_out) {
   h->solved = false;
   if (h->dtype == XMCA_F32) solve_impl<float>(h, n_fields, n_vec);
   else solve_impl<double>(h, n_fields, n_vec);
+  if (n_fields == 1) h->res.ldv[1] = 0;      // (a one-field result has no right vectors: xmca_rotate_solved stacks by ldv)
   h->solved = true;
   if (rank_out) *rank_out = h->res.rank;
   h->tm.collect();
@@ -954,6 +955,42 @@ int xmca_rotate_loadings(xmca_handle* h, const double* L, int64_t N, int64_t n_l
     XMCA_HIP(hipMemcpyAsync(B_out, Bd.get(), sizeof(double) * nl, hipMemcpyDeviceToHost, h->st));
     XMCA_HIP(hipStreamSynchronize(h->st));
   }
+  API_END(h)
+}
+
+int xmca_rotate_solved(xmca_handle* h, int p, int power, double tol, int max_iter, double* R_out, double* Phi_out,
+                       double* norm_left, double* norm_right, int* iters_out) {
+  API_BEGIN(h)
+  XMCA_CHECK(h->solved, XMCA_ERR_STATE, "rotate: no solve result on this handle");
+  XMCA_CHECK(p >= 2, XMCA_ERR_INVALID, "rotate: `n_rot` must be > 1");
+  XMCA_CHECK(power >= 1 && max_iter >= 1, XMCA_ERR_INVALID, "rotate: `power` must be >= 1");
+  const SolveResult& r = h->res;
+  XMCA_CHECK(p <= r.n_vec && r.ldv[0] > 0, XMCA_ERR_INVALID, "rotate: more modes requested than were back-projected");
+  const bool cplx = r.cplx;
+  const int64_t Nl = r.ldv[0], Nr = r.ldv[1] > 0 ? r.ldv[1] : 0;
+  Rotator rot(h->st, h->tm, h->gws, h->ews);
+  RotationDevice& d = h->rot;
+  rot.alloc(d, Nl + Nr, Nl, p, cplx);
+  DevBuf<double> sigma_dev;
+  XMCA_HIP(hipMemcpyAsync(sigma_dev.ensure((size_t)p), r.sigma.data(), sizeof(double) * p, hipMemcpyHostToDevice, h->st));
+  const CPlanes& Vl = r.Vt[0];
+  const CPlanes& Vr = r.Vt[Nr > 0 ? 1 : 0];
+  RotateResult rr;
+  // loadings of both fields stacked, V sqrt(sigma) (array.py:818-822), built where the vectors are
+  if (cplx) {
+    hipLaunchKernelGGL((rot_build_loadings_kernel<true>), ew_grid(Nl + Nr), dim3(EW_BLOCK), 0, h->st, Vl.r(), Vl.i(true), Nl, Nl,
+                       Vr.r(), Vr.i(true), Nr > 0 ? Nr : Nl, Nr, sigma_dev.get(), p, d.A.r(), d.A.i(true), d.h.get());
+    rot.run<true>(d, power, tol, max_iter, rr, nullptr, false);
+  } else {
+    hipLaunchKernelGGL((rot_build_loadings_kernel<false>), ew_grid(Nl + Nr), dim3(EW_BLOCK), 0, h->st, Vl.r(), (const double*)nullptr,
+                       Nl, Nl, Vr.r(), (const double*)nullptr, Nr > 0 ? Nr : Nl, Nr, sigma_dev.get(), p, d.A.r(), (double*)nullptr,
+                       d.h.get());
+    rot.run<false>(d, power, tol, max_iter, rr, nullptr, false);
+  }
+  h->tm.collect();
+  if (iters_out) *iters_out = rr.iters;
+  check_rot(rr);
+  fill_rot_outputs(rr, cplx, R_out, Phi_out, norm_left, norm_right, iters_out);
   API_END(h)
 }
 
