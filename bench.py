@@ -270,8 +270,9 @@ def main():
         ms_trd = trd_ms / trd_calls
         tf = flops_trd / ms_trd / 1e9
         resident = trd_resident >= trd_calls
-        roofline = {"kernel": ("trd_resident_kernel<real,NC=%d,RR=4> (Householder tridiagonalisation of the T x T Gram matrix, ONE "
-                               "persistent launch, matrix resident in registers, one grid exchange per column)" % (8 * -(-T // 1024))
+        roofline = {"kernel": ("trd_resident_kernel<real,NC=%d,RR=%d,tagged> (Householder tridiagonalisation of the T x T Gram matrix, ONE "
+                               "persistent launch, matrix resident in registers, one grid exchange per column)"
+                               % (8 * -(-T // 1024), -(-T // 1024))
                                if resident else "trd_step_kernel (Householder tridiagonalisation, one launch per column)"),
                     "bound": "mfma", "achieved": tf, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / F64_MFMA_PEAK_TF,
                     "note": "float64 vector FMAs (vector peak = matrix peak = 78.6 TF on MI355X); latency-bound by design: T "

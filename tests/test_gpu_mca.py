@@ -587,6 +587,29 @@ def test_varimax_hand_over_from_the_persistent_kernel(monkeypatch, name, cplx, n
     assert _rel(m._rotation_matrix, R) < 1e-9 and _rel(m._variance, var) < 1e-9
 
 
+@pytest.mark.parametrize("name,cplx,n_rot,power", [("unit_both", False, 8, 1), ("wide_both", True, 6, 4), ("unit_left", False, 5, 2),
+                                                   ("unit_left", True, 18, 1)])
+def test_rotate_on_resident_vectors_equals_rotate_on_fetched_loadings(name, cplx, n_rot, power):
+    """rotate() right after solve() builds the stacked loadings V sqrt(s) (array.py:818-822) from the singular vectors that
+    are still on the device (xmca_rotate_solved); once the vectors have been fetched it uploads the loadings built on the
+    host (xmca_rotate_loadings).  Same rotation either way: iteration count, R, Phi, norms."""
+    from xmca_amd.array import _LazyVectors
+    fields = make_input(name)
+    m = MCA(*fields)
+    m.solve(complexify=cplx)
+    assert isinstance(m._V, _LazyVectors) and m._V._pending == set(m._keys)       # nothing fetched yet: the device path
+    m.rotate(n_rot, power)
+    assert m._V._pending == set(m._keys)                                          # ... and rotate() fetched nothing
+    got = (m._varimax_iterations, m.rotation_matrix().copy(), m.correlation_matrix().copy(), m.norm(), m.variance().copy())
+    m._V.materialize()                                                            # now the host path
+    m.rotate(n_rot, power)
+    assert m._varimax_iterations == got[0]
+    assert _rel(m.rotation_matrix(), got[1]) < 1e-10 and _rel(m.correlation_matrix(), got[2]) < 1e-10
+    assert _rel(m.variance(), got[4]) < 1e-10
+    for k in m._keys:
+        assert _rel(m.norm()[k], got[3][k]) < 1e-10
+
+
 def test_unconverged_eigensolver_raises_like_gesdd(monkeypatch):
     """the Jacobi sweeps either reach their stopping rule or the solve raises LinAlgError (numpy's 'SVD did not
     converge'): an unconverged basis is never returned as singular vectors."""

@@ -104,6 +104,27 @@ def test_varimax_many_modes_matches_oracle(hip, n, p, cplx, seed):
     assert _rel(out["B"], B_ref) < TOL
 
 
+@pytest.mark.parametrize("n,p,cplx,seed", [(20000, 20, True, 71), (30000, 24, False, 72), (12000, 32, True, 73)])
+def test_varimax_wide_grid_and_two_stage_sum(hip, monkeypatch, n, p, cplx, seed):
+    """16 < p <= 32 on many grid points: the wide grid (up to one workgroup per CU), the unrolled accumulation, the
+    padded Newton-Schulz tiles and the two-stage sum of the partial G matrices (each entry added up by one workgroup, in a
+    fixed order).  Against the numpy restatement of rotation.py, and the all-to-all sum must stop at the same iteration."""
+    from oracle import ref_numpy as O
+    A = _wide_loadings(n, p, cplx, seed)
+    B_ref, R_ref, n_iter = O.varimax(A)
+    outs = {}
+    for form in ("1", "0"):
+        monkeypatch.setenv("XMCA_ROT_TWO_STAGE", form)
+        outs[form] = hip.rotate_loadings(A, n_left=n // 2, varimax_only=True, want_B=True)
+        assert outs[form]["n_iter"] == n_iter
+        assert _rel(outs[form]["R"], R_ref) < TOL
+        assert _rel(outs[form]["B"], B_ref) < TOL
+    assert _rel(outs["1"]["R"], outs["0"]["R"]) < 1e-12
+    monkeypatch.delenv("XMCA_ROT_TWO_STAGE")
+    again = hip.rotate_loadings(A, n_left=n // 2, varimax_only=True, want_B=True)
+    assert np.array_equal(again["R"], outs["1"]["R"])            # (default = two stages here; fixed summation order: same bits)
+
+
 @pytest.mark.parametrize("tag,gamma", [("r10", 0.0), ("r10", 0.5), ("c4", 0.0), ("c10p4", 0.3), ("r4", 1.0)])
 def test_varimax_gamma_family_matches_oracle(hip, tag, gamma):
     """`varimax(A, gamma)` (rotation.py:15, :56-57): gamma = 1 Varimax, 0 Quartimax, anything in between - same

@@ -452,6 +452,7 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
   __shared__ double red[TRD_RES_THREADS / 64];
   __shared__ double gam_sh[TRD_RES_THREADS / 64][2];
   __shared__ double dj_sh;
+  __shared__ double rowpart[2][TRD_RES_THREADS / 64][2];     // streamed rows: the waves' shares of row . v
   __shared__ int give_up_sh;
   constexpr int LV = NC * 128;                     // slots per vector = padded matrix order
   constexpr int NS = LV / TRD_RES_THREADS;         // slots per thread
@@ -700,82 +701,99 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
     double* const nrr = rb_r[prev];
     double* const nri = rb_i[prev];
     const unsigned int tgn = trd_tag_of(j + 1);      // what is published now is consumed by column j+1
-    // early rows (i < first_res, owner wave i mod NW): the same from global memory - first, so that their stores are on
-    // their way while the resident rows are processed (the drain before the flag waits for every store of the wave)
+    // early rows (i < first_res: complex problems of more than 2048 rows), owner WORKGROUP i mod nwg: the same from global
+    // memory, the live chunks of the row dealt to the four waves (one wave alone needs five dependent trips to memory for
+    // a row of 20 chunks: 9 us, which every other workgroup then waits for).  First, so that the stores are on their way
+    // while the resident rows are processed.  The partial sums of the waves are added in wave order.
     {
-      int i = g;
-      if (i < j + 1) i += ((j + 1 - i + NW - 1) / NW) * NW;
-      for (; i < first_res; i += NW) {
+      constexpr int MC = (NC + 3) / 4;               // chunks per wave and row, at most
+      int i = (int)blockIdx.x;
+      if (i < j + 1) i += ((j + 1 - i + nwg - 1) / nwg) * nwg;
+      int par = 0;
+      for (; i < first_res; i += nwg, par ^= 1) {
         const double svr_ = bV[0][i], swr_ = bW[0][i];
         const double svi_ = CPLX ? bV[1][i] : 0.0, swi_ = CPLX ? bW[1][i] : 0.0;
         double* rowr = P.Ar + (int64_t)i * P.ld;
         double* rowi = CPLX ? P.Ai + (int64_t)i * P.ld : nullptr;
         double sr = 0.0, si = 0.0;
         const bool pubrow = i == j + 1;
-        // four chunks per trip, their loads requested together (one wave streams a whole row: latency-bound otherwise)
-        for (int kb = 128 * c0; kb < LV; kb += 4 * 128) {
-          double2 la[4], lb[4];
+        // (at most four chunks of a wave in flight - 32 registers next to the resident rows; a fifth takes a second trip)
+#pragma unroll 1
+        for (int u0 = 0; u0 < MC; u0 += 4) {
+        double2 la[4], lb[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int k = kb + 128 * u + 2 * lane;
-            la[u] = make_double2(0.0, 0.0);
-            lb[u] = make_double2(0.0, 0.0);
-            if (k < LV) {
-              la[u] = *reinterpret_cast<const double2*>(rowr + k);
-              if (CPLX) lb[u] = *reinterpret_cast<const double2*>(rowi + k);
-            }
+        for (int uu = 0; uu < 4; ++uu) {
+          const int u = u0 + uu;
+          const int c = u < MC ? c0 + wave + 4 * u : NC;
+          la[uu] = make_double2(0.0, 0.0);
+          lb[uu] = make_double2(0.0, 0.0);
+          if (c < NC) {                              // (wave-uniform)
+            la[uu] = *reinterpret_cast<const double2*>(rowr + 128 * c + 2 * lane);
+            if (CPLX) lb[uu] = *reinterpret_cast<const double2*>(rowi + 128 * c + 2 * lane);
           }
+        }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int k = kb + 128 * u + 2 * lane;
-            if (k < LV) {
-              double2 a = la[u];
-              const double2 wk = *reinterpret_cast<const double2*>(bW[0] + k);
-              const double2 vk = *reinterpret_cast<const double2*>(bV[0] + k);
-              const double2 xk = *reinterpret_cast<const double2*>(bX[0] + k);
-              if (CPLX) {
-                double2 b = lb[u];
-                const double2 wki = *reinterpret_cast<const double2*>(bW[1] + k);
-                const double2 vki = *reinterpret_cast<const double2*>(bV[1] + k);
-                const double2 xki = *reinterpret_cast<const double2*>(bX[1] + k);
-                a.x -= (svr_ * wk.x + svi_ * wki.x) + (swr_ * vk.x + swi_ * vki.x);
-                b.x -= (svi_ * wk.x - svr_ * wki.x) + (swi_ * vk.x - swr_ * vki.x);
-                a.y -= (svr_ * wk.y + svi_ * wki.y) + (swr_ * vk.y + swi_ * vki.y);
-                b.y -= (svi_ * wk.y - svr_ * wki.y) + (swi_ * vk.y - swr_ * vki.y);
-                *reinterpret_cast<double2*>(rowr + k) = a;
-                *reinterpret_cast<double2*>(rowi + k) = b;
-                sr += a.x * xk.x - b.x * xki.x;
-                si += a.x * xki.x + b.x * xk.x;
-                sr += a.y * xk.y - b.y * xki.y;
-                si += a.y * xki.y + b.y * xk.y;
-                if (pubrow) {
-                  trd_st_sc1(nri + k, TAG ? trd_tagged(b.x, tgn) : b.x);
-                  trd_st_sc1(nri + k + 1, TAG ? trd_tagged(b.y, tgn) : b.y);
-                }
-              } else {
-                a.x -= svr_ * wk.x + swr_ * vk.x;
-                a.y -= svr_ * wk.y + swr_ * vk.y;
-                *reinterpret_cast<double2*>(rowr + k) = a;
-                sr += a.x * xk.x;
-                sr += a.y * xk.y;
-              }
+        for (int uu = 0; uu < 4; ++uu) {
+          const int u = u0 + uu;
+          const int c = u < MC ? c0 + wave + 4 * u : NC;
+          if (c < NC) {
+            const int k = 128 * c + 2 * lane;
+            double2 a = la[uu];
+            const double2 wk = *reinterpret_cast<const double2*>(bW[0] + k);
+            const double2 vk = *reinterpret_cast<const double2*>(bV[0] + k);
+            const double2 xk = *reinterpret_cast<const double2*>(bX[0] + k);
+            if (CPLX) {
+              double2 b = lb[uu];
+              const double2 wki = *reinterpret_cast<const double2*>(bW[1] + k);
+              const double2 vki = *reinterpret_cast<const double2*>(bV[1] + k);
+              const double2 xki = *reinterpret_cast<const double2*>(bX[1] + k);
+              a.x -= (svr_ * wk.x + svi_ * wki.x) + (swr_ * vk.x + swi_ * vki.x);
+              b.x -= (svi_ * wk.x - svr_ * wki.x) + (swi_ * vk.x - swr_ * vki.x);
+              a.y -= (svr_ * wk.y + svi_ * wki.y) + (swr_ * vk.y + swi_ * vki.y);
+              b.y -= (svi_ * wk.y - svr_ * wki.y) + (swi_ * vk.y - swr_ * vki.y);
+              *reinterpret_cast<double2*>(rowr + k) = a;
+              *reinterpret_cast<double2*>(rowi + k) = b;
+              sr += a.x * xk.x - b.x * xki.x;
+              si += a.x * xki.x + b.x * xk.x;
+              sr += a.y * xk.y - b.y * xki.y;
+              si += a.y * xki.y + b.y * xk.y;
               if (pubrow) {
-                trd_st_sc1(nrr + k, TAG ? trd_tagged(a.x, tgn) : a.x);
-                trd_st_sc1(nrr + k + 1, TAG ? trd_tagged(a.y, tgn) : a.y);
+                trd_st_sc1(nri + k, TAG ? trd_tagged(b.x, tgn) : b.x);
+                trd_st_sc1(nri + k + 1, TAG ? trd_tagged(b.y, tgn) : b.y);
               }
+            } else {
+              a.x -= svr_ * wk.x + swr_ * vk.x;
+              a.y -= svr_ * wk.y + swr_ * vk.y;
+              *reinterpret_cast<double2*>(rowr + k) = a;
+              sr += a.x * xk.x;
+              sr += a.y * xk.y;
+            }
+            if (pubrow) {
+              trd_st_sc1(nrr + k, TAG ? trd_tagged(a.x, tgn) : a.x);
+              trd_st_sc1(nrr + k + 1, TAG ? trd_tagged(a.y, tgn) : a.y);
             }
           }
         }
-        const double yr = trd_wave_sum_dpp(sr);
-        const double yi = CPLX ? trd_wave_sum_dpp(si) : 0.0;
-        const double pr = tr * yr - ti * yi, pi = tr * yi + ti * yr;
-        const double vr = bX[0][i], vi = CPLX ? bX[1][i] : 0.0;
-        if (lane == 0) {
-          trd_st_sc1(pbr + i, TAG ? trd_tagged(pr, tgn) : pr);
-          if (CPLX) trd_st_sc1(pbi + i, TAG ? trd_tagged(pi, tgn) : pi);
         }
-        gwr += pr * vr + pi * vi;
-        gwi += pr * vi - pi * vr;
+        sr = trd_wave_sum_dpp(sr);
+        if (CPLX) si = trd_wave_sum_dpp(si);
+        if (lane == 0) {
+          rowpart[par][wave][0] = sr;
+          rowpart[par][wave][1] = si;
+        }
+        __syncthreads();
+        if (wave == 0) {
+          const double yr = ((rowpart[par][0][0] + rowpart[par][1][0]) + rowpart[par][2][0]) + rowpart[par][3][0];
+          const double yi = CPLX ? ((rowpart[par][0][1] + rowpart[par][1][1]) + rowpart[par][2][1]) + rowpart[par][3][1] : 0.0;
+          const double pr = tr * yr - ti * yi, pi = tr * yi + ti * yr;
+          const double vr = bX[0][i], vi = CPLX ? bX[1][i] : 0.0;
+          if (lane == 0) {
+            trd_st_sc1(pbr + i, TAG ? trd_tagged(pr, tgn) : pr);
+            if (CPLX) trd_st_sc1(pbi + i, TAG ? trd_tagged(pi, tgn) : pi);
+          }
+          gwr += pr * vr + pi * vi;
+          gwi += pr * vi - pi * vr;
+        }
       }
     }
     if (first_res + g + NW * (RR - 1) > j) {        // (uniform) the wave still owns a live resident row
