@@ -829,8 +829,8 @@ __device__ __forceinline__ void ns_tile(const int ksteps, const double* __restri
                                         const int b0, const int sb, const int last_a, const int last_b, const double last_mask,
                                         d4_t& acc_r, d4_t& acc_i) {
 #define XMCA_NS_CASE(KS) case KS: ns_tile_unrolled<CPLX, TSTEP, KS>(Ar, Ai, Br, Bi, a0, sa, b0, sb, last_a, last_b, last_mask, acc_r, acc_i); break;
-  switch (ksteps) {   // 16 < p <= 64
-    XMCA_NS_CASE(5) XMCA_NS_CASE(6) XMCA_NS_CASE(7) XMCA_NS_CASE(8) XMCA_NS_CASE(9) XMCA_NS_CASE(10) XMCA_NS_CASE(11)
+  switch (ksteps) {   // p <= 64 (1 .. 4: the tail's A0 R of few modes)
+    XMCA_NS_CASE(1) XMCA_NS_CASE(2) XMCA_NS_CASE(3) XMCA_NS_CASE(4) XMCA_NS_CASE(5) XMCA_NS_CASE(6) XMCA_NS_CASE(7) XMCA_NS_CASE(8) XMCA_NS_CASE(9) XMCA_NS_CASE(10) XMCA_NS_CASE(11)
     XMCA_NS_CASE(12) XMCA_NS_CASE(13) XMCA_NS_CASE(14) XMCA_NS_CASE(15) XMCA_NS_CASE(16)
     default: break;
   }
@@ -997,7 +997,51 @@ __device__ __forceinline__ void varimax_polar_step(double* __restrict__ sm, cons
   // (16 loads in flight - the partials come from L2 after the acquire), the slices are then added in order.
   const int nsl = pp <= 128 ? 256 / pp : 1;
   double fro2 = 0.0;
-  if (nsl > 1) {
+  const int pairs = pp >> 1;
+  if (nwg > 1 && (pp & 1) == 0 && pairs <= 64) {
+    // few modes, even p^2: two entries per load, four slices of the workgroups, 20 loads in flight - one or two trips to L2
+    // instead of three or more (C2: 79 partials of 100 entries).  Slice sl adds the workgroups sl, sl + 4, ... in order, the
+    // slices are then added in order: one fixed summation order per entry.
+    const int sl = tid / pairs, e2 = tid - sl * pairs;
+    if (sl < 4) {
+      double2 sr = make_double2(0.0, 0.0), si = make_double2(0.0, 0.0);
+      for (int w0 = sl; w0 < nwg; w0 += 20 * 4) {
+        double2 vr[20], vi[20];
+#pragma unroll
+        for (int u = 0; u < 20; ++u) {
+          const int ww = w0 + 4 * u;
+          vr[u] = make_double2(0.0, 0.0);
+          vi[u] = make_double2(0.0, 0.0);
+          if (ww < nwg) {
+            vr[u] = *reinterpret_cast<const double2*>(part_r + (int64_t)ww * pp + 2 * e2);
+            if constexpr (CPLX) vi[u] = *reinterpret_cast<const double2*>(part_i + (int64_t)ww * pp + 2 * e2);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 20; ++u) {
+          sr.x += vr[u].x; sr.y += vr[u].y;
+          if constexpr (CPLX) { si.x += vi[u].x; si.y += vi[u].y; }
+        }
+      }
+      scr[sl * pp + 2 * e2] = sr.x;
+      scr[sl * pp + 2 * e2 + 1] = sr.y;
+      if constexpr (CPLX) {
+        scr[512 + sl * pp + 2 * e2] = si.x;
+        scr[512 + sl * pp + 2 * e2 + 1] = si.y;
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < pp; e += 256) {
+      const double sr = ((scr[e] + scr[pp + e]) + scr[2 * pp + e]) + scr[3 * pp + e];
+      Gr[e] = sr;
+      fro2 += sr * sr;
+      if constexpr (CPLX) {
+        const double si = ((scr[512 + e] + scr[512 + pp + e]) + scr[512 + 2 * pp + e]) + scr[512 + 3 * pp + e];
+        Gi[e] = si;
+        fro2 += si * si;
+      }
+    }
+  } else if (nsl > 1) {
     const int sl = tid / pp, e = tid % pp;
     if (sl < nsl) {
       double sr = 0.0, si = 0.0;
@@ -1195,7 +1239,7 @@ __device__ __forceinline__ void varimax_polar_step(double* __restrict__ sm, cons
     for (int k = 1; k < p; ++k) hmin = fmin(hmin, scr[512 + k]);
     state[6] = 0.5 * hmin * inv;                  // next iteration's guess (ignored unless within (1e-6, 1))
   }
-  if (p > 16) {
+  {
     // prod = Re conj(R) . (A0 R), the product as MFMA tiles like the Newton-Schulz Y step (operands: A0 staged in T, R in X)
     __syncthreads();
     for (int t = wv; t < PT * PT; t += 4) {
@@ -1212,23 +1256,6 @@ __device__ __forceinline__ void varimax_polar_step(double* __restrict__ sm, cons
         }
       }
     }
-  }
-  for (int e = tid; p <= 16 && e < pp; e += 256) {
-    const int j = e / p, k = e % p;
-    double tr = 0.0, ti = 0.0;
-#pragma unroll 5
-    for (int l = 0; l < p; ++l) {
-      const double ar = Tr[j * p + l], rr = Xr[l * p + k];
-      tr += ar * rr;
-      if constexpr (CPLX) {
-        const double ai = Ti[j * p + l], ri = Xi[l * p + k];
-        tr -= ai * ri;
-        ti += ar * ri + ai * rr;
-      }
-    }
-    double prod = Xr[e] * tr;
-    if constexpr (CPLX) prod += Xi[e] * ti;
-    Yr[e] = prod;
   }
   __syncthreads();
   for (int k = tid; k < p; k += 256) {
@@ -1286,6 +1313,121 @@ __global__ __launch_bounds__(256) void varimax_iter_kernel(const double* __restr
 #endif
   ROT_STAMP(2);
   varimax_polar_step<CPLX>(sm, part_r, part_i, (int)gridDim.x, p, A0r, A0i, Rr, Ri, cvec, state, tol);
+}
+
+// The accumulation below for p <= 16 (one mode tile) with every loop unrolled: KS = ceil(p / 4) summation steps in the Z
+// product.  Wave w owns the points 16 w .. 16 w + 15 of a tile for BOTH stages: in the C/D layout of the MFMA register r of
+// lane (l4, l15) holds Z[point l4 + 4 r][mode l15], which is exactly the B operand of summation step r of G = A^H W - so W
+// never leaves the registers, and a tile costs neither an LDS round trip nor a barrier (the general form: W to LDS, barrier,
+// W back, run-time loops: 8.9k cycles per iteration at C2 for 14 MFMAs per wave).  The four partial G of the waves are
+// added in wave order at the end.
+template <bool CPLX, int KS>
+__device__ __forceinline__ void varimax_accum_mfma_pt1(double* __restrict__ sm, const double* __restrict__ Ar,
+                                                       const double* __restrict__ Ai, const int64_t N, const int p,
+                                                       const double* __restrict__ Rr, const double* __restrict__ Ri,
+                                                       const double* __restrict__ cvec, double* __restrict__ out_r,
+                                                       double* __restrict__ out_i, double* __restrict__ res_r,
+                                                       double* __restrict__ res_i, const bool res_ready, const double gamma) {
+  const int pl = p * ROT_LDP, pp = p * p;
+  double* Yr = sm + pl;                   // (the layout of varimax_accum_mfma: Xs, tile, R copy, weights per plane)
+  double* Yi = sm + 3 * pl + pp + ROT_PB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+  // B operands of Z = A R:  R[4 s + l4][l15], zero outside p x p
+  double rbr[KS], rbi[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int j = 4 * s + l4;
+    const bool in = j < p && l15 < p;
+    const int idx = in ? j * p + l15 : 0;
+    const double vr = Rr[idx], vi = CPLX ? Ri[idx] : 0.0;
+    rbr[s] = in ? vr : 0.0;
+    rbi[s] = in ? vi : 0.0;
+  }
+  const double cn = l15 < p ? gamma * (cvec[l15] / (double)N) : 0.0;
+  const bool gjin = l15 < p;
+  const int gja = (gjin ? l15 : 0) * ROT_LDP + wave * 16 + l4;     // A operand of G: conj(A[j = l15][16 w + 4 s + l4])
+  d4_t gr = {0, 0, 0, 0}, gi = {0, 0, 0, 0};
+
+  const int64_t nbatch = (N + ROT_PB - 1) / ROT_PB;
+  for (int64_t bt = blockIdx.x; bt < nbatch; bt += gridDim.x) {
+    const int64_t n0 = bt * ROT_PB;
+    double* Tr = Yr;
+    double* Ti = Yi;
+    if (res_r) {
+      const int64_t bl = (bt - blockIdx.x) / gridDim.x;
+      Tr = res_r + bl * pl;
+      Ti = res_i + bl * pl;
+    }
+    if (!res_r || !res_ready) {
+      __syncthreads();                    // the staging buffer is no longer read
+      for (int e = tid; e < p * ROT_PB; e += 256) {
+        const int j = e / ROT_PB, pt = e % ROT_PB;
+        const int64_t n = n0 + pt;
+        double vr = 0.0, vi = 0.0;
+        if (n < N) {
+          vr = Ar[(int64_t)j * N + n];
+          if constexpr (CPLX) vi = Ai[(int64_t)j * N + n];
+        }
+        Tr[j * ROT_LDP + pt] = vr;
+        if constexpr (CPLX) Ti[j * ROT_LDP + pt] = vi;
+      }
+      __syncthreads();
+    }
+    double ar[KS], ai[KS], qa[4], qb[4];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int j = 4 * s + l4;
+      const bool jin = j < p;
+      const int a = (jin ? j : 0) * ROT_LDP + wave * 16 + l15;
+      const double vr = Tr[a], vi = CPLX ? Ti[a] : 0.0;
+      ar[s] = jin ? vr : 0.0;
+      ai[s] = jin ? vi : 0.0;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const double va = Tr[gja + 4 * s], vb = CPLX ? Ti[gja + 4 * s] : 0.0;
+      qa[s] = gjin ? va : 0.0;
+      qb[s] = gjin ? vb : 0.0;
+    }
+    d4_t zr = {0, 0, 0, 0}, zi = {0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      zr = Mfma<double>::mma(ar[s], rbr[s], zr);
+      if constexpr (CPLX) {
+        zi = Mfma<double>::mma(ar[s], rbi[s], zi);
+        zr = Mfma<double>::mma(-ai[s], rbi[s], zr);
+        zi = Mfma<double>::mma(ai[s], rbr[s], zi);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      // W = (|z|^2 - c_k / N) z     (rotation.py:56-57);  G[j][k] += sum_pt conj(A[pt][j]) W[pt][k], step r = points l4 + 4 r
+      const double f = zr[r] * zr[r] + zi[r] * zi[r] - cn;
+      const double wr = f * zr[r], wi = f * zi[r];
+      gr = Mfma<double>::mma(qa[r], wr, gr);
+      if constexpr (CPLX) {
+        gi = Mfma<double>::mma(qa[r], wi, gi);
+        gr = Mfma<double>::mma(qb[r], wi, gr);      // conj(a) w
+        gi = Mfma<double>::mma(-qb[r], wr, gi);
+      }
+    }
+  }
+  __syncthreads();      // the tiles are no longer read: the scratch below may overlap them
+  double* scr_r = sm;                 // [wave][p][p]
+  double* scr_i = sm + 4 * pp;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int j = l4 + 4 * r, k = l15;
+    if (j < p && k < p) {
+      scr_r[wave * pp + j * p + k] = gr[r];
+      if constexpr (CPLX) scr_i[wave * pp + j * p + k] = gi[r];
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < pp; e += 256) {
+    out_r[e] = ((scr_r[e] + scr_r[pp + e]) + scr_r[2 * pp + e]) + scr_r[3 * pp + e];
+    if constexpr (CPLX) out_i[e] = ((scr_i[e] + scr_i[pp + e]) + scr_i[2 * pp + e]) + scr_i[3 * pp + e];
+  }
 }
 
 // The accumulation below for 16 < p <= 32 (two mode tiles per dimension) with every loop unrolled: KS = ceil(p / 4) summation
@@ -1457,6 +1599,14 @@ __device__ __forceinline__ void varimax_accum_mfma(double* __restrict__ sm, cons
   double* Rsi = Yi + pl;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
   const int PT = (p + 15) / 16;
+  if (PT == 1) {
+    switch ((p + 3) >> 2) {
+      case 1: varimax_accum_mfma_pt1<CPLX, 1>(sm, Ar, Ai, N, p, Rr, Ri, cvec, out_r, out_i, res_r, res_i, res_ready, gamma); return;
+      case 2: varimax_accum_mfma_pt1<CPLX, 2>(sm, Ar, Ai, N, p, Rr, Ri, cvec, out_r, out_i, res_r, res_i, res_ready, gamma); return;
+      case 3: varimax_accum_mfma_pt1<CPLX, 3>(sm, Ar, Ai, N, p, Rr, Ri, cvec, out_r, out_i, res_r, res_i, res_ready, gamma); return;
+      default: varimax_accum_mfma_pt1<CPLX, 4>(sm, Ar, Ai, N, p, Rr, Ri, cvec, out_r, out_i, res_r, res_i, res_ready, gamma); return;
+    }
+  }
   if (PT == 2) {
     switch ((p + 3) >> 2) {
       case 5: varimax_accum_mfma_pt2<CPLX, 5>(sm, Ar, Ai, N, p, Rr, Ri, cvec, out_r, out_i, res_r, res_i, res_ready, gamma); return;
