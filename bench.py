@@ -56,6 +56,10 @@ def _cap_host_threads():
             break
         except (OSError, ValueError, IndexError):
             continue
+    try:                                        # several ranks on one node share the quota
+        n = max(1, n // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))
+    except ValueError:
+        pass
     for v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
         os.environ.setdefault(v, str(n))
     return n
