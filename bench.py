@@ -66,6 +66,10 @@ def _cap_host_threads():
 
 
 HOST_THREADS = _cap_host_threads()          # before numpy / torch load their thread pools
+if os.environ.get("LOCAL_WORLD_SIZE", "1") not in ("", "1"):
+    # several ranks on one node: the library's waits sleep on an interrupt instead of spinning (1.4 host cores per rank while
+    # the GPU works, more with the surrogate lanes of rule_n - enough to exhaust a container's CPU quota: csrc/common.h)
+    os.environ.setdefault("XMCA_BLOCKING_SYNC", "1")
 
 import numpy as np   # noqa: E402
 

@@ -76,6 +76,14 @@ int xmca_create(int device, xmca_handle** out) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) { (void)hipGetLastError(); return XMCA_ERR_HIP; }
   if (hipSetDevice(device) != hipSuccess) return XMCA_ERR_HIP;
+  // XMCA_BLOCKING_SYNC=1: the host threads of this process sleep on an interrupt while they wait for the device instead of
+  // spinning (measured: 1.4 host cores per process while the GPU works -> 0.5; +0.3 ms per 14 ms eigensolve).  For several
+  // ranks / surrogate lanes sharing few host cores: a cgroup CPU quota exhausted by spinning threads stalls every thread of
+  // the container for the rest of the period ("Host threads"); bench.py sets it for runs of several ranks.
+  {
+    const char* e = std::getenv("XMCA_BLOCKING_SYNC");
+    if (e && e[0] == '1') { (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync); (void)hipGetLastError(); }
+  }
   xmca_handle* h = new xmca_handle();
   h->device = device;
   if (hipStreamCreate(&h->st) != hipSuccess) { delete h; return XMCA_ERR_HIP; }
