@@ -281,3 +281,25 @@ def test_randomised_models_at_multi_tile_size_match_oracle():
     r = subprocess.run([sys.executable, os.path.join(repo, "scripts", "fuzz_solve.py"), "14", "11", "300,640,1000"], capture_output=True,
                        text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_blocking_sync_switch_changes_nothing_but_the_waiting():
+    """XMCA_BLOCKING_SYNC=1 (several ranks per node under a CPU quota: host threads sleep while they wait for the GPU,
+    hipDeviceScheduleBlockingSync at xmca_create) is read when a process creates its first handle - so in a fresh process:
+    same singular values, bit for bit, as this one."""
+    import subprocess
+    import sys
+    from xmca_amd.array import MCA
+    left, right = make_input("wide_both")
+    m = MCA(left, right)
+    m.solve()
+    here = m.singular_values()
+    code = ("import sys; sys.path[:0] = %r; import numpy as np; from golden_inputs import make_input; "
+            "from xmca_amd.array import MCA; l, r = make_input('wide_both'); m = MCA(l, r); m.solve(); "
+            "np.save(sys.argv[1], m.singular_values())") % [p for p in sys.path if p]
+    out = os.path.join(os.environ.get("TMPDIR", "/tmp"), "xmca_blocking_sync_sv_%d.npy" % os.getpid())
+    env = dict(os.environ, XMCA_BLOCKING_SYNC="1")
+    subprocess.run([sys.executable, "-c", code, out], check=True, env=env, timeout=600)
+    there = np.load(out)
+    os.remove(out)
+    assert np.array_equal(here, there)

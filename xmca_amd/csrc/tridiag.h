@@ -424,6 +424,7 @@ struct TrdSync {
   unsigned int* flags;    // epoch per workgroup
   int* give_up;
   int poll_delay;         // 64-cycle units to sleep before the first poll (polling early only disturbs the publishers)
+  int tag_delay;          // tagged exchange: 64-cycle units to sleep before the loads of a column are requested
 };
 
 
@@ -513,6 +514,10 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
     if (!TAG && tid < nwg) {
       gr = trd_ld_sc1(gp_r[prev] + tid);
       if (CPLX) gi = trd_ld_sc1(gp_i[prev] + tid);
+    }
+    if (TAG && j > 0) {
+      // (a request that arrives before the values costs a whole round trip: better to ask a little later)
+      for (int q = 0; q < S.tag_delay; ++q) __builtin_amdgcn_s_sleep(1);
     }
     double lr_[NS], li_[NS], lp_[NS], lq_[NS];
 #pragma unroll
@@ -1202,12 +1207,14 @@ inline TrdParams trd_reduce(hipStream_t st, TrdWorkspace& ws, const double* Ar, 
     for (int a = 0; a < 2; ++a) for (int c = 0; c < 2; ++c) { S.rowbuf[a][c] = q; q += lv; }
     S.flags = ws.flags.get();
     { const char* e = std::getenv("XMCA_TRD_POLL_DELAY"); S.poll_delay = e ? std::atoi(e) : 16; }
+    { const char* e = std::getenv("XMCA_TRD_TAG_DELAY"); S.tag_delay = e ? std::max(0, std::min(256, std::atoi(e))) : (cplx ? 32 : 24); }   // (real: 0 -> 23.4 ms at n = 2920, 4.77 at 1000; 24 -> 22.4, 3.72)
     // column 0 reads its row like every other column: from rowbuf (parity 0)
     // (the tagged form reads row 0 from the working copy: the exchange buffers must start as zeros)
-    // exchange by tagged values or by epoch flags.  Measured (n = 2920 real / 2501 complex): tagged 24.9 / 36.7 ms, flags 25.4 /
-    // 32.6 ms - four planes per slot have to arrive for a complex column - so: real problems tagged, complex ones flags
-    // (XMCA_TRD_TAGGED=1 / 0 forces one form for both)
-    const bool tagged = [cplx] { const char* e = std::getenv("XMCA_TRD_TAGGED"); return e ? e[0] != '0' : !cplx; }();
+    // exchange by tagged values or by epoch flags.  Measured with the request delay tuned (XMCA_TRD_TAG_DELAY), tagged / flags:
+    // real n = 1000 3.7 / 5.0 ms, 2920 22.4 / 25.4; complex n = 1000 5.7 / 6.9, 2048 19.0 / 20.4, 2501 (NC = 20: 60 bytes of
+    // spills in the tagged build, streamed rows) 29.4 / 28.1 - so: flags for the largest complex instantiation only
+    // (XMCA_TRD_TAGGED=1 / 0 forces one form for everything)
+    const bool tagged = [cplx, nc] { const char* e = std::getenv("XMCA_TRD_TAGGED"); return e ? e[0] != '0' : !(cplx && nc >= 20); }();
     if (!tagged) {
       XMCA_HIP(hipMemcpyAsync(S.rowbuf[0][0], P.Ar, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
       if (cplx) XMCA_HIP(hipMemcpyAsync(S.rowbuf[0][1], P.Ai, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
