@@ -855,6 +855,25 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      // the next column's row first (it is on every workgroup's critical path): published as stored, update j is applied by
+      // the consumers
+#pragma unroll
+      for (int t = 0; t < RR; ++t) {
+        if (first_res + g + NW * t == j + 1) {             // wave-uniform
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            if (c >= c0) {
+              const int k = 128 * c + 2 * lane;
+              trd_st_sc1(nrr + k, TAG ? trd_tagged(ar[t][c].x, tgn) : ar[t][c].x);
+              trd_st_sc1(nrr + k + 1, TAG ? trd_tagged(ar[t][c].y, tgn) : ar[t][c].y);
+              if (CPLX) {
+                trd_st_sc1(nri + k, TAG ? trd_tagged(ai[t][c].x, tgn) : ai[t][c].x);
+                trd_st_sc1(nri + k + 1, TAG ? trd_tagged(ai[t][c].y, tgn) : ai[t][c].y);
+              }
+            }
+          }
+        }
+      }
 #pragma unroll
       for (int t = 0; t < RR; ++t) {
         const int i = first_res + g + NW * t;
@@ -869,20 +888,6 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
           }
           gwr += pr * vr + pi * vi;
           gwi += pr * vi - pi * vr;
-          if (i == j + 1) {                              // the next column's row: publish it as stored (update j applied next time)
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-              if (c >= c0) {
-                const int k = 128 * c + 2 * lane;
-                trd_st_sc1(nrr + k, TAG ? trd_tagged(ar[t][c].x, tgn) : ar[t][c].x);
-                trd_st_sc1(nrr + k + 1, TAG ? trd_tagged(ar[t][c].y, tgn) : ar[t][c].y);
-                if (CPLX) {
-                  trd_st_sc1(nri + k, TAG ? trd_tagged(ai[t][c].x, tgn) : ai[t][c].x);
-                  trd_st_sc1(nri + k + 1, TAG ? trd_tagged(ai[t][c].y, tgn) : ai[t][c].y);
-                }
-              }
-            }
-          }
         }
       }
     }
