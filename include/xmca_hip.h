@@ -66,6 +66,9 @@ int xmca_complexify(xmca_handle* h, const double* hilbert_col);
 /* MCA.solve numerical core (xmca/array.py:549-584): per-field SVD, kernel, kernel SVD, back-projection.
  *   n_fields  1 (EOF/PCA) or 2 (MCA)
  *   n_vec     number of leading modes to back-project into grid space; -1 = all `rank` modes
+ *             (two float64 fields: the re-solve of weak modes - deflation / weak-block refinement, DESIGN.md 1 - covers the
+ *             modes that get vectors; with 0 <= n_vec < rank the singular values beyond n_vec are those of the single solve,
+ *             accurate to ~5e-14 (sigma_1 / sigma_i)^2 relative)
  *   rank_out  min(T, Nx, Ny)  (array.py:597) */
 int xmca_solve(xmca_handle* h, int n_fields, int64_t n_vec, int64_t* rank_out);
 
