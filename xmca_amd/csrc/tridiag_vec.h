@@ -5,10 +5,11 @@
 //      z(i+1) = -(e_i / D-_{i+1}) z(i) downwards (Parlett & Dhillon; LAPACK dlar1v without the RRR shifts).  With an
 //      eigenvalue accurate to eps ||T|| the residual is eps ||T||; vectors of close eigenvalues are orthogonal only to
 //      eps ||T|| / gap - the clean-up below restores that;
-//   2. back-transformation with blocks of 64 reflectors in compact WY form, Z -= V (T (V^H Z)), the two tall products MFMA
+//   2. back-transformation with blocks of 128 reflectors in compact WY form, Z -= V (T (V^H Z)), the two tall products MFMA
 //      GEMMs.  T is never formed: its inverse is explicit, T^{-1} = striu(V^H V) + diag(1 / tau) (from T^{-1} + T^{-H} =
 //      V^H V), so T W is a back substitution per column (trd_wy_solve_kernel), and V^H V comes out of the same product as
-//      W = V^H Z (the reflectors ride along as 64 extra columns of Z);
+//      W = V^H Z (the reflectors ride along as 128 extra columns of Z); the 128 x 128 system is solved in two halves of 64
+//      with one small product in between;
 //   3. S = Z^H Z; max |S - I| decides: <= 0.3 -> one or two Newton-Schulz steps Z <- Z (3/2 I - 1/2 S) (the last one
 //      written as (3/2 I - 1/2 S)(rows reversed) Z^H, i.e. straight into the caller's layout: row i = conj(u_i), eigenvalues
 //      descending); otherwise (clusters the twisted vectors cannot resolve: repeated eigenvalues, exact null spaces of
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(128) void trd_twisted_kernel(const double* __restri
   }
 }
 
-// Zext[i][r] = Vs[r][i] (i < mb, r < 64; zero for r >= nb): the block's reflectors as 64 extra columns of Z, so that ONE
+// Zext[i][r] = Vs[r][i] (i < mb, r < 64; zero for r >= nb): 64 of the block's reflectors as extra columns of Z, so that ONE
 // product V^H [Z | V] gives both W = V^H Z and the Gram matrix V^H V
 __global__ void trd_vcopy_kernel(const double* __restrict__ Vr, const double* __restrict__ Vi, int64_t ldv, int nb, int mb,
                                  double* __restrict__ Er, double* __restrict__ Ei, int64_t lde) {
@@ -164,18 +165,20 @@ __global__ void trd_vcopy_kernel(const double* __restrict__ Vr, const double* __
 
 // X = T W for one block of reflectors without forming T: T^{-1} = M = striu(V^H V) + diag(1 / tau) is explicit, so every
 // column of W is back-substituted through M (one thread per column, M in LDS, the column in registers).
-// Wx: 64 x ldw planes; columns [0, n) hold W and are overwritten by X, columns [n, n + 64) hold V^H V.
+// Wx: 64 x ldw planes; columns [0, n) hold W and are overwritten by X, columns [scol, scol + 64) hold V^H V.
 template <bool CPLX>
 __global__ __launch_bounds__(128) void trd_wy_solve_kernel(double* __restrict__ Wr, double* __restrict__ Wi, int64_t ldw, int n, int nb,
-                                                           const double* __restrict__ taur, const double* __restrict__ taui) {
+                                                           const double* __restrict__ taur, const double* __restrict__ taui, int scol) {
+  // scol: first column of this block's V^H V inside the rows of Wx (n for a block of <= 64 reflectors; the halves of a block
+  // of 128 pass their own diagonal block of the 128 x 128 Gram matrix)
   __shared__ double mr[64][64], mi[CPLX ? 64 : 1][64];
   for (int e = threadIdx.x; e < 64 * 64; e += blockDim.x) {
     const int r = e >> 6, c = e & 63;
     double a = 0.0, b = 0.0;
     if (r < nb && c < nb) {
       if (c > r) {
-        a = Wr[(int64_t)r * ldw + n + c];
-        if (CPLX) b = Wi[(int64_t)r * ldw + n + c];
+        a = Wr[(int64_t)r * ldw + scol + c];
+        if (CPLX) b = Wi[(int64_t)r * ldw + scol + c];
       } else if (c == r) {
         // the diagonal holds 1 / M_rr = tau_r (tau = 0: the stored reflector is the zero vector, any finite value does)
         a = taur[r];
@@ -283,7 +286,10 @@ inline bool trd_eigenvectors(hipStream_t st, TrdWorkspace& ws, TrdVecWorkspace& 
                              double* Zr, double* Zi, int64_t ldz) {
   const int n = P.n;
   const int64_t ldv = P.ld;                                   // reflectors
-  const int64_t ld = ((int64_t)n + 64 + 15) & ~(int64_t)15;   // Z with 64 extra columns (the block's reflectors, see trd_vcopy_kernel)
+  // reflectors per block of the back-transformation: 128 (two skinny GEMMs per block at twice the depth, half the passes over
+  // Z; the 128 x 128 system T^{-1} X = W is solved in two halves of 64 with one small product in between) or 64
+  const int NBK = [] { const char* e = std::getenv("XMCA_TRD_WY_BLOCK"); return (e && std::atoi(e) == 64) ? 64 : 128; }();
+  const int64_t ld = ((int64_t)n + NBK + 15) & ~(int64_t)15;   // Z with NBK extra columns (the block's reflectors, see trd_vcopy_kernel)
   const size_t plane = (size_t)n * ld;
   double* Yr = vw.Y[0].ensure(plane);
   double* Yi = cplx ? vw.Y[1].ensure(plane) : nullptr;
@@ -293,23 +299,39 @@ inline bool trd_eigenvectors(hipStream_t st, TrdWorkspace& ws, TrdVecWorkspace& 
   XMCA_HIP(hipGetLastError());
   if (cplx) XMCA_HIP(hipMemsetAsync(Yi, 0, sizeof(double) * plane, st));
   // ---- Z = H_0 H_1 ... H_{n-2} Yt, blocks of 64 reflectors from the last to the first:  Z -= V (T (V^H Z)) ----
-  double* sm = vw.small.ensure(2 * (size_t)64 * ld);
-  double* Wbr = sm; double* Wbi = Wbr + 64 * ld;
+  double* sm = vw.small.ensure(2 * (size_t)NBK * ld);
+  double* Wbr = sm; double* Wbi = Wbr + (size_t)NBK * ld;
   const int nref = n - 1;
-  for (int j0 = ((nref - 1) / 64) * 64; j0 >= 0; j0 -= 64) {
-    const int nb = std::min(64, nref - j0);
+  auto solve = [&](int row0, int rows, int scol, int jtau) {   // X = T W for the rows [row0, row0 + rows) of the block, in place
+    double* wr = Wbr + (int64_t)row0 * ld;
+    double* wi = cplx ? Wbi + (int64_t)row0 * ld : nullptr;
+    if (cplx) hipLaunchKernelGGL(trd_wy_solve_kernel<true>, dim3(ceil_div(n, 128)), dim3(128), 0, st, wr, wi, ld, n, rows, P.tau[0] + jtau, P.tau[1] + jtau, scol);
+    else hipLaunchKernelGGL(trd_wy_solve_kernel<false>, dim3(ceil_div(n, 128)), dim3(128), 0, st, wr, nullptr, ld, n, rows, P.tau[0] + jtau, nullptr, scol);
+  };
+  for (int j0 = ((nref - 1) / NBK) * NBK; j0 >= 0; j0 -= NBK) {
+    const int nb = std::min(NBK, nref - j0);
     const int i0 = j0 + 1, mb = n - i0;                      // support of the block: rows i0 .. n-1
     const double* Vbr = P.Vr + (int64_t)j0 * ldv + i0;       // Vs[r][i - i0], r < nb  (row-major, k fast)
     const double* Vbi = cplx ? P.Vi + (int64_t)j0 * ldv + i0 : nullptr;
     double* Zr0 = Yr + (int64_t)i0 * ld;
     double* Zi0 = cplx ? Yi + (int64_t)i0 * ld : nullptr;
-    hipLaunchKernelGGL(trd_vcopy_kernel, dim3(ceil_div(mb, 64)), dim3(256), 0, st, Vbr, Vbi, ldv, nb, mb, Zr0 + n, cplx ? Zi0 + n : nullptr, ld);
-    // [W | S] = V^H [Z | V]  (nb x (n + 64)):  W[r][k] = sum_i conj(Vs[r][i]) Z[i][k]
-    cgemm<double>(st, gws, Vbr, Vbi, ldv, true, true, Zr0, Zi0, ld, true, false, Wbr, cplx ? Wbi : nullptr, ld, nb, n + 64, mb, 1.0, nullptr,
+    for (int h = 0; h < NBK; h += 64)                         // (zero columns for the reflectors a short last block does not have)
+      hipLaunchKernelGGL(trd_vcopy_kernel, dim3(ceil_div(mb, 64)), dim3(256), 0, st, Vbr + (int64_t)h * ldv, cplx ? Vbi + (int64_t)h * ldv : nullptr,
+                         ldv, std::max(0, std::min(64, nb - h)), mb, Zr0 + n + h, cplx ? Zi0 + n + h : nullptr, ld);
+    // [W | S] = V^H [Z | V]  (nb x (n + NBK)):  W[r][k] = sum_i conj(Vs[r][i]) Z[i][k]
+    cgemm<double>(st, gws, Vbr, Vbi, ldv, true, true, Zr0, Zi0, ld, true, false, Wbr, cplx ? Wbi : nullptr, ld, nb, n + NBK, mb, 1.0, nullptr,
                   nullptr, false);
-    // X = T W, in place
-    if (cplx) hipLaunchKernelGGL(trd_wy_solve_kernel<true>, dim3(ceil_div(n, 128)), dim3(128), 0, st, Wbr, Wbi, ld, n, nb, P.tau[0] + j0, P.tau[1] + j0);
-    else hipLaunchKernelGGL(trd_wy_solve_kernel<false>, dim3(ceil_div(n, 128)), dim3(128), 0, st, Wbr, nullptr, ld, n, nb, P.tau[0] + j0, nullptr);
+    // X = T W, in place:  T^{-1} = M = striu(S) + diag(1 / tau) is upper triangular - the rows from 64 on first, then they are
+    // taken out of the first 64 rows (W_1 -= M_12 X_2), then those
+    if (nb > 64) {
+      const int h2 = nb - 64;
+      solve(64, h2, n + 64, j0 + 64);
+      cgemm<double>(st, gws, Wbr + n + 64, cplx ? Wbi + n + 64 : nullptr, ld, true, false, Wbr + (int64_t)64 * ld, cplx ? Wbi + (int64_t)64 * ld : nullptr, ld,
+                    true, false, Wbr, cplx ? Wbi : nullptr, ld, 64, n, h2, -1.0, nullptr, nullptr, false, 1.0);
+      solve(0, 64, n, j0);
+    } else {
+      solve(0, nb, n, j0);
+    }
     // Z[i0:, :] -= V X      (A(m = i, k = r) = Vs[r][i]: the k-slow orientation)
     cgemm<double>(st, gws, Vbr, Vbi, ldv, false, false, Wbr, cplx ? Wbi : nullptr, ld, true, false, Zr0, Zi0, ld, mb, n, nb, -1.0, nullptr,
                   nullptr, false, 1.0);
