@@ -163,6 +163,53 @@ __global__ void trd_vcopy_kernel(const double* __restrict__ Vr, const double* __
   }
 }
 
+// Row R of the back substitution x_R = (w_R - sum_{l > R} M[R][l] x_l) tau_R and, recursively, the rows below it in the order
+// R, R-1, ..., 0.  The multipliers M[R][l] (LDS, the same for every thread) are requested 16 at a time BEFORE the FMAs that use
+// them: left to itself the compiler waits for every LDS operand in turn (one s_waitcnt per two FMAs: 36 us per block of 64
+// real reflectors).  Everything is indexed at compile time: x stays in registers.
+template <bool CPLX, int R>
+struct trd_wy_rows {
+  template <int L0>
+  static __device__ __forceinline__ void chunk(const double (&xr)[64], const double (&xi)[CPLX ? 64 : 1], const double (*mr)[64],
+                                               const double (*mi)[64], double& sr, double& si) {
+    if constexpr (L0 < 64) {
+      if constexpr (L0 + 15 > R) {
+        double mcr[16], mci[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          mcr[u] = mr[R][L0 + u];
+          mci[u] = CPLX ? mi[R][L0 + u] : 0.0;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          if (L0 + u > R) {
+            if constexpr (CPLX) {
+              sr -= mcr[u] * xr[L0 + u] - mci[u] * xi[L0 + u];
+              si -= mcr[u] * xi[L0 + u] + mci[u] * xr[L0 + u];
+            } else {
+              sr -= mcr[u] * xr[L0 + u];
+            }
+          }
+        }
+      }
+      chunk<L0 + 16>(xr, xi, mr, mi, sr, si);
+    }
+  }
+  static __device__ __forceinline__ void run(double (&xr)[64], double (&xi)[CPLX ? 64 : 1], const double (*mr)[64], const double (*mi)[64]) {
+    double sr = xr[R], si = CPLX ? xi[R] : 0.0;
+    chunk<0>(xr, xi, mr, mi, sr, si);
+    // x_R = s / M_RR = s * tau_R (the diagonal of the LDS copy holds tau)
+    if constexpr (CPLX) {
+      xr[R] = sr * mr[R][R] - si * mi[R][R];
+      xi[R] = sr * mi[R][R] + si * mr[R][R];
+    } else {
+      xr[R] = sr * mr[R][R];
+    }
+    if constexpr (R > 0) trd_wy_rows<CPLX, R - 1>::run(xr, xi, mr, mi);
+  }
+};
+
 // X = T W for one block of reflectors without forming T: T^{-1} = M = striu(V^H V) + diag(1 / tau) is explicit, so every
 // column of W is back-substituted through M (one thread per column, M in LDS, the column in registers).
 // Wx: 64 x ldw planes; columns [0, n) hold W and are overwritten by X, columns [scol, scol + 64) hold V^H V.
@@ -171,22 +218,35 @@ __global__ __launch_bounds__(128) void trd_wy_solve_kernel(double* __restrict__ 
                                                            const double* __restrict__ taur, const double* __restrict__ taui, int scol) {
   // scol: first column of this block's V^H V inside the rows of Wx (n for a block of <= 64 reflectors; the halves of a block
   // of 128 pass their own diagonal block of the 128 x 128 Gram matrix)
-  __shared__ double mr[64][64], mi[CPLX ? 64 : 1][64];
-  for (int e = threadIdx.x; e < 64 * 64; e += blockDim.x) {
-    const int r = e >> 6, c = e & 63;
-    double a = 0.0, b = 0.0;
-    if (r < nb && c < nb) {
-      if (c > r) {
-        a = Wr[(int64_t)r * ldw + scol + c];
-        if (CPLX) b = Wi[(int64_t)r * ldw + scol + c];
-      } else if (c == r) {
-        // the diagonal holds 1 / M_rr = tau_r (tau = 0: the stored reflector is the zero vector, any finite value does)
-        a = taur[r];
-        if (CPLX) b = taui[r];
-      }
+  __shared__ __attribute__((aligned(16))) double mr[64][64], mi[CPLX ? 64 : 1][64];
+  // (every load of a phase requested before the first use: unconditional loads from clamped addresses, selected afterwards)
+  {
+    constexpr int PER = 64 * 64 / 128;
+    double ga[PER], gb[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int e = threadIdx.x + 128 * q, r = e >> 6, c = e & 63;
+      const int rr = r < nb ? r : 0, cc = c < nb ? c : 0;
+      ga[q] = Wr[(int64_t)rr * ldw + scol + cc];
+      gb[q] = CPLX ? Wi[(int64_t)rr * ldw + scol + cc] : 0.0;
     }
-    mr[r][c] = a;
-    if (CPLX) mi[r][c] = b;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int e = threadIdx.x + 128 * q, r = e >> 6, c = e & 63;
+      double a = 0.0, b = 0.0;
+      if (r < nb && c < nb) {
+        if (c > r) {
+          a = ga[q];
+          b = gb[q];
+        } else if (c == r) {
+          // the diagonal holds 1 / M_rr = tau_r (tau = 0: the stored reflector is the zero vector, any finite value does)
+          a = taur[r];
+          if (CPLX) b = taui[r];
+        }
+      }
+      mr[r][c] = a;
+      if (CPLX) mi[r][c] = b;
+    }
   }
   __syncthreads();
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -194,29 +254,12 @@ __global__ __launch_bounds__(128) void trd_wy_solve_kernel(double* __restrict__ 
   double xr[64], xi[CPLX ? 64 : 1];
 #pragma unroll
   for (int r = 0; r < 64; ++r) {
-    xr[r] = r < nb ? Wr[(int64_t)r * ldw + k] : 0.0;
-    if (CPLX) xi[r] = r < nb ? Wi[(int64_t)r * ldw + k] : 0.0;
+    const int rr = r < nb ? r : 0;
+    const double vr = Wr[(int64_t)rr * ldw + k], vi = CPLX ? Wi[(int64_t)rr * ldw + k] : 0.0;
+    xr[r] = r < nb ? vr : 0.0;
+    if (CPLX) xi[r] = r < nb ? vi : 0.0;
   }
-#pragma unroll
-  for (int r = 63; r >= 0; --r) {
-    double sr = xr[r], si = CPLX ? xi[r] : 0.0;
-#pragma unroll
-    for (int l = r + 1; l < 64; ++l) {
-      if (CPLX) {
-        sr -= mr[r][l] * xr[l] - mi[r][l] * xi[l];
-        si -= mr[r][l] * xi[l] + mi[r][l] * xr[l];
-      } else {
-        sr -= mr[r][l] * xr[l];
-      }
-    }
-    // x_r = s / M_rr = s * tau_r
-    if (CPLX) {
-      xr[r] = sr * mr[r][r] - si * mi[r][r];
-      xi[r] = sr * mi[r][r] + si * mr[r][r];
-    } else {
-      xr[r] = sr * mr[r][r];
-    }
-  }
+  trd_wy_rows<CPLX, 63>::run(xr, xi, mr, mi);
 #pragma unroll
   for (int r = 0; r < 64; ++r) {
     if (r < nb) {
