@@ -47,6 +47,24 @@ def test_eigenvalues_only_match_lapack(hip, monkeypatch, n, cplx, resident):
     assert np.array_equal(lam, again)                       # fixed summation order: the same bits
 
 
+@pytest.mark.parametrize("n,cplx", [(130, False), (193, True), (1000, False), (900, True)])
+def test_back_transformation_block_sizes_agree(hip, monkeypatch, n, cplx):
+    """Blocks of 128 reflectors (default: the 128 x 128 WY system solved as two halves of 64 with one product in between; the last
+    block is shorter, here also shorter than 64 or just above it) against blocks of 64: the same eigenvectors to rounding."""
+    monkeypatch.setenv("XMCA_TRIDIAG_VEC_MIN_N", "2")
+    G = _gram(n, cplx)
+    lam, U = hip.eigh(G)
+    assert hip.last_eigh_info["tridiag"] == 1
+    monkeypatch.setenv("XMCA_TRD_WY_BLOCK", "64")
+    lam64, U64 = hip.eigh(G)
+    assert hip.last_eigh_info["tridiag"] == 1
+    assert np.array_equal(lam, lam64)
+    assert np.max(np.abs(U.conj().T @ U - np.eye(n))) < 1e-12 and np.max(np.abs(U64.conj().T @ U64 - np.eye(n))) < 1e-12
+    # the same vectors up to the rounding of two different summation orders (well separated part of the spectrum)
+    ov = np.abs(np.sum(U[:, :20].conj() * U64[:, :20], axis=0))
+    assert np.max(np.abs(ov - 1.0)) < 1e-10
+
+
 @pytest.mark.parametrize("resident", ["tagged", "flags", "0"])
 @pytest.mark.parametrize("n,cplx", [(70, False), (200, True), (777, False), (1000, True), (1500, False)])
 def test_eigenvectors_match_lapack(hip, monkeypatch, n, cplx, resident):
