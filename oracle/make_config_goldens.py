@@ -13,6 +13,9 @@ Varimax iteration count) and the outputs are written to tests/golden/config_case
 leading unrotated vectors (float32 / complex64 storage: 6e-8 relative, far below the 1e-5 they are compared at), R,
 Phi, norms, variance, mode order, explained variance, rotated PCs, iteration count.
 
+  c4_run0     configs[3]: surrogate (seed 1, run 0) of rule_n at C4 size, T = 5000 x (20 000, 15 000), complexify, through the
+              real reference on the normals of oracle/philox_numpy.py (= the device generator) -> rule_n_c4_run0.npz
+
 Also: bootstrapping goldens (reference `MCA.bootstrapping(3, ...)` under `np.random.seed(5)`) for the five
 parameterisations of tests/test_gpu_mca.py -> tests/golden/bootstrap_cases.npz.
 """
@@ -138,6 +141,36 @@ def main():
         dst = os.path.join(OUT, "config_%s.npz" % name)
         np.savez_compressed(dst, **out)
         print("wrote %s (%.2f MB)" % (dst, os.path.getsize(dst) / 1e6))
+    if "c4_run0" in only:
+        # BASELINE configs[3]: ONE surrogate of rule_n on the C4 configuration, exactly the normals the device generates for
+        # (seed 1, run 0) - oracle/philox_numpy.py restates the generator - through the REAL reference (array.py:1753-1765).
+        # ~5 minutes and ~15 GB on 8 cores.  bench.py and tests/test_gpu_configs.py compare row 0 of xmca_rule_n with it.
+        from oracle.philox_numpy import surrogate_fields
+        Tn, widths, seed = 5000, (20000, 15000), 1
+        t0 = time.perf_counter()
+        fields = surrogate_fields(Tn, widths, seed, 0)
+        t1 = time.perf_counter()
+        m = MCA(*fields)
+        m.solve(complexify=True)
+        t2 = time.perf_counter()
+        out = {"T": np.asarray(Tn), "widths": np.asarray(widths), "seed": np.asarray(seed), "run": np.asarray(0),
+               "variance": np.asarray(m._get_variance(), dtype=np.float64),
+               "singular_values": np.asarray(m._singular_values, dtype=np.float64),
+               "first_normals_left": fields[0].ravel()[:64].copy(), "first_normals_right": fields[1].ravel()[:64].copy(),
+               "checksum_left": np.asarray(fields[0].sum()), "checksum_right": np.asarray(fields[1].sum())}
+        try:
+            m.rotate(20, 4)
+            out["rotated_dropped"] = np.asarray(0)
+            out["rotated_variance"] = np.asarray(m._get_variance(), dtype=np.float64)
+        except RuntimeError:
+            out["rotated_dropped"] = np.asarray(1)      # Varimax does not converge on complex white noise (array.py:1762-1763)
+        t3 = time.perf_counter()
+        out["cpu_seconds"] = np.asarray([t1 - t0, t2 - t1, t3 - t2])
+        print("c4_run0 reference: normals %.1f s, ctor + solve %.1f s, rotate %.1f s (dropped: %d)" %
+              (t1 - t0, t2 - t1, t3 - t2, int(out["rotated_dropped"])), flush=True)
+        dst = os.path.join(OUT, "rule_n_c4_run0.npz")
+        np.savez_compressed(dst, **out)
+        print("wrote %s (%.3f MB)" % (dst, os.path.getsize(dst) / 1e6))
     if not only or "bootstrap" in only:
         out = {}
         for tag, inp, single, cplx, rot, kw in BOOT:

@@ -1,27 +1,39 @@
-// MFMA GEMM for gfx950: C[MxN] = alpha * rs[m] * cs[n] * op(A) * op(B) + beta * C
+// MFMA GEMM for gfx950: C[MxN] = alpha * rs[m] * cs[n] * op(A) * op(B) + beta * C          (round 4: rewritten)
 //
-// * f64 operands -> v_mfma_f64_16x16x4_f64, f32 operands -> v_mfma_f32_16x16x4_f32
-//   (exact f32, flushed into f64 side accumulators every FLUSH_TILES k-tiles so that long contractions keep
-//   f64-class accumulation error: "WIDE").
-// * 128x128 block tile, BK = 32, 512 threads = 8 waves (2 x 4), each wave 64x32 = 4x2 MFMA tiles
-//   (~130 VGPRs -> two workgroups per CU).
-// * operands are staged global -> registers -> LDS (k-major, padded); the loads of the next k-tile are in flight
-//   while the current one feeds the matrix pipe.  Global reads are 16-byte vectors along the contiguous axis:
-//   a k-contiguous operand is read in 256-byte (f64) / 128-byte (f32) row segments.
-// * All four operand orientations of row-major storage are supported, so no transposed copy of a space x time
-//   field is ever materialised:
-//       A_KFAST: A(m,k) = A[m*lda + k]   else  A(m,k) = A[k*lda + m]
-//       B_NFAST: B(k,n) = B[k*ldb + n]   else  B(k,n) = B[n*ldb + k]
-// * upper_only: only block tiles with bn >= bm are launched (Gram / Hermitian products);
-//   mirror = +1/-1 writes the (anti)symmetric counterpart of off-diagonal tiles.
-// * the (split, tile) list is dealt to the 8 XCDs in contiguous ranges (workgroup b runs on XCD b % 8), so the
-//   workgroups sharing one L2 work on neighbouring tiles of the same k-slice.
-// * split-K through an f64 workspace + reduce kernel (deterministic).
+// * f64 operands -> v_mfma_f64_16x16x4_f64, f32 operands -> v_mfma_f32_16x16x4_f32 (exact f32, flushed into f64 side
+//   accumulators every 512 products so that long contractions keep f64-class accumulation error: "WIDE").
+// * 128 x 128 block tile, 256 threads = 4 waves (2 x 2), each wave a 64 x 64 tile = 4 x 4 MFMA tiles; two workgroups per CU
+//   (one wave of each on every SIMD, 256 registers per lane each: accumulators + side accumulators + two sets of fragments
+//   fit, no scratch).
+// * operands go global -> LDS by LDS-DMA (`global_load_lds`, 16 bytes per lane, no staging registers) into two stages of
+//   16 KB per operand (BK = 16 doubles / 32 floats = 128 bytes per row).  ONE barrier per k-tile, placed before the LAST
+//   phase of a tile: behind it the DMA of k-tile t + 2 is issued into the stage everybody has finished reading, the first
+//   fragments of k-tile t + 1 are requested, and the MFMAs of the last phase of t cover both.
+// * fragments are read one phase (8 contraction indices) ahead into a second register set, so no MFMA waits for LDS.
+// * LDS keeps the orientation of the global array, so nothing is transposed on the way in:
+//     K-fast operand  (A(m,k) = A[m*lda + k], B(k,n) = B[n*ldb + k]):  [row][BK], 128-byte rows, 16-byte chunks XOR-swizzled
+//         by (row >> 1) & 7 on the SOURCE address (the DMA writes lane-linear) and on the read;
+//     row-fast operand (A(m,k) = A[k*lda + m], B(k,n) = B[k*ldb + n]): [k][128]; f32: chunk bit 3 flipped on odd k-row pairs.
+//   Every fragment read fetches TWO elements per lane (ds_read_b128 for f64, ds_read_b64 for f32), conflict-free, and feeds
+//   two MFMAs: for a K-fast operand two consecutive k of one row (k = 2 * (lane >> 4) + step), for a row-fast operand two
+//   consecutive rows at one k, i.e. two interleaved MFMA tiles (the epilogue knows the interleaving).  Both use the same
+//   k <-> (step, lane) map, so all four orientation pairs share one kernel body.
+// * upper_only: only block tiles with bn >= bm are launched (Gram / Hermitian products); mirror = +1/-1 writes the
+//   (anti)symmetric counterpart of off-diagonal tiles.
+// * split-K inside the launch: every slice writes its raw f64 sums in register order (write-through 16-byte stores, 1 KB per
+//   instruction) to a workspace slab, drains them, takes a ticket on the tile's counter, and the LAST arriver (one
+//   agent-scope acquire) adds the slabs in slice order (bit-reproducible whatever the arrival order), applies the epilogue
+//   and resets the counter (cdna_hip_programming.md 5, "in-launch split-K reduction", sc1 form).  No reduce kernel.
+// * the (slice, tile) list is dealt to the 8 XCDs in contiguous ranges (workgroup b runs on XCD b % 8) and tiles are
+//   enumerated in 8 x 8 super-blocks, so the workgroups sharing one L2 work on neighbouring tiles of the same k-slice.
+// * unaligned operands (leading dimension or base not a multiple of 16 bytes) and the last, partial k-tile are staged
+//   through registers with predicated element loads (zero filled) into the same LDS image.
 //
-// Reference call sites this replaces: numpy `@` / gesdd inner products of
-// xmca/array.py:552-566 and :580-584 (see DESIGN.md for the formulation).
+// Reference call sites this replaces: numpy `@` / gesdd inner products of xmca/array.py:479, :552-566 and :580-584
+// (see DESIGN.md for the formulation).
 #pragma once
 #include <algorithm>
+#include <cmath>
 #include <memory>
 #include <type_traits>
 #include <vector>
@@ -33,14 +45,15 @@ namespace xmca {
 typedef double d4_t __attribute__((ext_vector_type(4)));
 typedef float f4_t __attribute__((ext_vector_type(4)));
 typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef float f2_t __attribute__((ext_vector_type(2)));
 
 template <typename T>
 struct Mfma;
 template <>
 struct Mfma<double> {
   using acc_t = d4_t;
-  using vec_t = d2_t;
-  static constexpr int VW = 2;
+  using vec_t = d2_t;      // one 16-byte chunk
+  using frag_t = d2_t;     // one fragment read: two elements
   static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
   }
@@ -51,7 +64,7 @@ template <>
 struct Mfma<float> {
   using acc_t = f4_t;
   using vec_t = f4_t;
-  static constexpr int VW = 4;
+  using frag_t = f2_t;
   static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
   }
@@ -59,13 +72,24 @@ struct Mfma<float> {
   static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) * 4 + r; }
 };
 
-constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 32, GEMM_THREADS = 512;
-// LDS row pitch (elements).  A k-contiguous operand is stored TRANSPOSED into the k-major LDS tile with scalar
-// writes: pitch 129 puts the 16 (f64) / 32 (f32) lanes of a write group on distinct banks.  An m/n-contiguous operand
-// is stored with 16-byte vector writes: pitch 132 keeps every row 16-byte aligned for f32 and f64.
-template <bool FAST_K>
-struct GemmPitch { static constexpr int value = FAST_K ? 129 : 132; };
-constexpr int GEMM_FLUSH_TILES = 16;  // WIDE: f32 partial sums cover at most 16 * 32 = 512 products
+constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_THREADS = 256;
+constexpr int GEMM_STAGE_BYTES = 16384;     // one operand, one stage: 128 rows x 128 bytes
+// WIDE (f32 operands): three levels of accumulation.  The MFMA accumulators take at most 512 products, are then added
+// (f32) into a second set of f32 sums, which takes at most 32 such blocks = 16 384 products = one k-slice; longer
+// contractions are ALWAYS cut into slices of at most that length, and slices are added in f64 (slabs, last arriver).
+// Rounding: 512 products in f32 ~ sqrt(512) eps/2 relative to the block sum (random walk; 1.3e-6), 32 block sums another
+// sqrt(32) eps/2 (3.4e-7), averaged over the 32 blocks: ~4e-7 per slice, ~4e-7 / sqrt(slices) for the whole contraction -
+// 5e-8 at K = 1 036 800 (C5) - against eps/2 = 6e-8 of each f32 input element.  Round 1-3 flushed into f64 side
+// accumulators instead (3e-8 at C5): 128 more registers per lane, which left no room for the second fragment set.
+constexpr int GEMM_FLUSH_PRODUCTS = 512;
+constexpr int GEMM_SLICE_PRODUCTS = 16384;
+template <typename T>
+struct GemmK {
+  static constexpr int E = (int)sizeof(T);
+  static constexpr int CE = 16 / E;                 // elements per 16-byte chunk
+  static constexpr int BK = 128 / E;                // 16 doubles / 32 floats
+  static constexpr int NPH = BK / 8;                // phases per k-tile: 8 contraction indices = 2 MFMA k-steps each
+};
 
 template <typename TI, typename TO>
 struct GemmParams {
@@ -79,85 +103,107 @@ struct GemmParams {
   const double* col_scale;  // nullable, length N
   int upper_only;
   int mirror;
-  int k_chunk;              // contraction length handled by one split
-  int64_t split_stride;     // elements between consecutive split-K slices of C
-  int n_tiles;              // block tiles per split (upper triangle only when upper_only)
+  int k_chunk;              // contraction length handled by one slice (multiple of BK)
+  int splits;
+  int n_tiles;              // block tiles per slice (upper triangle only when upper_only)
   int n_wg;                 // n_tiles * splits
   const int* tile_map;      // n_tiles packed (bm << 16 | bn) in super-block order
-  int vec_a, vec_b;         // 16-byte vector loads allowed (base and leading dimension aligned)
+  int vec_a, vec_b;         // 16-byte LDS-DMA allowed (base and leading dimension aligned, tile offsets fit 32 bits)
+  double* slabs;            // split-K: [splits][n_tiles][128 * 128] raw sums in register order
+  int* counters;            // split-K: arrival tickets, one per tile, zero between launches
 };
 
-// One (128 x 32) operand tile: 8 elements per thread as NV vectors of VW.
-//   FAST_K: the global array is contiguous along k (row index = m/n), else contiguous along m/n (row index = k).
-template <typename TI, bool FAST_K>
-struct GemmTileIO {
-  static constexpr int VW = Mfma<TI>::VW, NV = 8 / VW;
-  static constexpr int PITCH = GemmPitch<FAST_K>::value;
-  using vec_t = typename Mfma<TI>::vec_t;
-  // position of vector i of this thread inside the tile: r along the 128-wide axis, k along the contraction axis
-  static __device__ __forceinline__ void pos(int i, int& r, int& k) {
-    const int v = i * GEMM_THREADS + (int)threadIdx.x;
-    if constexpr (FAST_K) { r = v / (GEMM_BK / VW); k = (v % (GEMM_BK / VW)) * VW; }
-    else                  { k = v / (GEMM_BM / VW); r = (v % (GEMM_BM / VW)) * VW; }
-  }
-  // interior tile: unpredicated 16-byte loads from a per-thread base pointer (tile origin already applied)
-  static __device__ __forceinline__ void load_fast(const TI* __restrict__ base, int64_t ld, TI (&reg)[8]) {
-    int r0, k0;
-    pos(0, r0, k0);
-    const TI* p0 = FAST_K ? base + (int64_t)r0 * ld + k0 : base + (int64_t)k0 * ld + r0;
-    // consecutive vectors of a thread are a fixed number of rows apart
-    constexpr int STEP = FAST_K ? GEMM_THREADS / (GEMM_BK / VW) : GEMM_THREADS / (GEMM_BM / VW);
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const vec_t x = *reinterpret_cast<const vec_t*>(p0 + (int64_t)i * STEP * ld);
-#pragma unroll
-      for (int j = 0; j < VW; ++j) reg[i * VW + j] = x[j];
+// One operand of the product: where its 16-byte chunks sit in a 16 KB LDS stage, how they are fetched, and which element
+// of the 64-wide wave tile an MFMA operand lane holds.
+template <typename TI, bool KFAST>
+struct GemmOperand {
+  static constexpr int E = GemmK<TI>::E, CE = GemmK<TI>::CE, BK = GemmK<TI>::BK;
+  using frag_t = typename Mfma<TI>::frag_t;
+  // LDS byte offset o (multiple of 16) of a stage -> (row r of the 128-wide axis, first contraction index k) of the chunk
+  static __device__ __forceinline__ void where(int o, int& r, int& k) {
+    if constexpr (KFAST) {
+      r = o >> 7;
+      k = (((o >> 4) & 7) ^ ((r >> 1) & 7)) * CE;
+    } else {
+      k = o / (128 * E);
+      int c = (o % (128 * E)) >> 4;
+      if constexpr (E == 4) c ^= ((k >> 1) & 1) << 3;
+      r = c * CE;
     }
   }
-  // edge tile / unaligned operand: element-wise, zero filled
-  static __device__ __forceinline__ void load_slow(const TI* __restrict__ P, int64_t ld, int row0, int rows, int k0, int kend,
-                                                   TI (&reg)[8]) {
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      int r, k;
-      pos(i, r, k);
-#pragma unroll
-      for (int j = 0; j < VW; ++j) {
-        const int er = row0 + (FAST_K ? r : r + j), ek = k0 + (FAST_K ? k + j : k);
-        TI x = TI(0);
-        if (er < rows && ek < kend) x = FAST_K ? P[(int64_t)er * ld + ek] : P[(int64_t)ek * ld + er];
-        reg[i * VW + j] = x;
-      }
+  // LDS-DMA instruction q = 4 * wave + j of a stage (fills the LDS bytes [1024 q, 1024 q + 1024), lane l the 16 bytes at
+  // 1024 q + 16 l): byte offset of the lane's chunk relative to the tile origin at k0 = voff(lane, j & 1) + soff(wave, j);
+  // the same map as where(), split into a lane part (two registers: even / odd j) and a scalar part
+  static __device__ __forceinline__ uint32_t voff(int lane, int jpar, int64_t ld) {
+    if constexpr (KFAST) return (uint32_t)((lane >> 3) * ld * E + (((lane & 7) ^ (((lane >> 4) + 4 * jpar) & 7)) << 4));
+    else if constexpr (E == 8) return (uint32_t)(lane * 16);
+    else return (uint32_t)((lane >> 5) * ld * E + (((lane & 31) ^ (jpar << 3)) << 4));
+  }
+  static __device__ __forceinline__ uint32_t soff(int wave, int j, int64_t ld) {
+    const int q = 4 * wave + j;
+    return (uint32_t)((KFAST ? 8 : (E == 8 ? 1 : 2)) * q * ld * E);
+  }
+  // bytes from the tile origin at k0 to the end of the operand (R rows of the 128-wide axis, K contraction indices): the
+  // buffer descriptor's range.  Rows beyond the matrix come back as zeros instead of being read (their results are never
+  // stored).  A row-fast chunk that straddles row R reads on into the next k-row - garbage for a row that is never stored
+  // - which exists for every k-row but the last: see `ragged` in the kernel.
+  static __device__ __forceinline__ uint32_t remaining(int R, int row0, int K, int k0, int64_t ld) {
+    const int64_t n = KFAST ? ((int64_t)(R - 1 - row0) * ld + (K - k0)) * E : ((int64_t)(K - 1 - k0) * ld + (R - row0)) * E;
+    return n > 0xffffffffll ? 0xffffffffu : (uint32_t)n;
+  }
+  // LDS byte address (within a stage) of fragment read f (0..3) of phase q for this lane = frag_addr(frag_base(w0, lane), q, f)
+  // with q, f compile-time: one register per operand, the rest is immediates and one XOR.  w0 = 0 / 64: the wave's origin.
+  //   K-fast:   f = 16-row block: two consecutive k (k = 8 q + 2 kk + {0, 1}) of row w0 + 16 f + i; the chunk index
+  //             (8 q + 2 kk) * E / 16 = (4 q | kk) for f64, (2 q | kk >> 1) for f32 is XORed with the row's swizzle, and the
+  //             phase bits are disjoint from the lane bits, so the phase enters as an XOR of the byte address
+  //   row-fast: f = 2 * step + u: rows w0 + 32 u + 2 i, + 1 at k = 8 q + 2 kk + step; f32 rows (512 bytes) flip chunk bit 3
+  //             (byte bit 7) on k-rows with (k >> 1) & 1 = kk & 1, which makes u an XOR as well
+  static __device__ __forceinline__ int frag_base(int w0, int lane) {
+    const int i = lane & 15, kk = lane >> 4;
+    if constexpr (KFAST) {
+      const int byteoff = 2 * kk * E;
+      return (w0 + i) * 128 + (((byteoff >> 4) ^ ((i >> 1) & 7)) << 4) + (byteoff & 15);
+    } else {
+      const int g = (w0 >> 1) + i;               // pair index along the row axis (u = 0)
+      if constexpr (E == 8) return 2 * kk * 1024 + g * 16;
+      else return 2 * kk * 512 + (((g >> 1) ^ ((kk & 1) << 3)) << 4) + (g & 1) * 8;
     }
   }
-  static __device__ __forceinline__ void store(TI (*S)[PITCH], const TI (&reg)[8]) {
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      int r, k;
-      pos(i, r, k);
-      if constexpr (FAST_K) {
-#pragma unroll
-        for (int j = 0; j < VW; ++j) S[k + j][r] = reg[i * VW + j];
-      } else {
-        vec_t x;
-#pragma unroll
-        for (int j = 0; j < VW; ++j) x[j] = reg[i * VW + j];
-        *reinterpret_cast<vec_t*>(&S[k][r]) = x;
-      }
-    }
+  static __device__ __forceinline__ int frag_addr(int base, int q, int f) {
+    if constexpr (KFAST) return (base ^ (q * 8 * E)) + f * 2048;
+    else if constexpr (E == 8) return base + (8 * q + (f >> 1)) * 1024 + (f & 1) * 256;
+    else return (base ^ ((f & 1) << 7)) + (8 * q + (f >> 1)) * 512;
+  }
+  // operand of MFMA tile t (0..3) at k-step e (0..1) out of the four fragments of a phase
+  static __device__ __forceinline__ TI value(const frag_t (&f)[4], int e, int t) {
+    if constexpr (KFAST) return f[t][e];
+    else return f[2 * e + (t >> 1)][t & 1];
+  }
+  // position (0..63) inside the wave tile of index x16 (0..15) of MFMA tile t
+  static __device__ __forceinline__ int index(int t, int x16) {
+    if constexpr (KFAST) return 16 * t + x16;
+    else return 32 * (t >> 1) + 2 * x16 + (t & 1);
   }
 };
 
-// MINW = minimum waves per SIMD the register allocation must allow: 4 -> two 512-thread workgroups per CU
-// (<= 128 VGPRs), 2 -> one workgroup per CU.
-template <typename TI, typename TO, bool A_KFAST, bool B_NFAST, bool WIDE, int MINW>
-__global__ __launch_bounds__(GEMM_THREADS, MINW) void gemm_kernel(GemmParams<TI, TO> p) {
+static __device__ __forceinline__ int gemm_lane_id() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
+template <typename TI, typename TO, bool A_KFAST, bool B_NFAST, bool WIDE>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams<TI, TO> p) {
   using M_ = Mfma<TI>;
   using acc_t = typename M_::acc_t;
-  using IOA = GemmTileIO<TI, A_KFAST>;
-  using IOB = GemmTileIO<TI, !B_NFAST>;
-  __shared__ __attribute__((aligned(16))) TI As[GEMM_BK][IOA::PITCH];
-  __shared__ __attribute__((aligned(16))) TI Bs[GEMM_BK][IOB::PITCH];
+  using vec_t = typename M_::vec_t;
+  using frag_t = typename M_::frag_t;
+  using OA = GemmOperand<TI, A_KFAST>;
+  using OB = GemmOperand<TI, !B_NFAST>;
+  constexpr int CE = GemmK<TI>::CE, BK = GemmK<TI>::BK, NPH = GemmK<TI>::NPH, E = GemmK<TI>::E, SB = GEMM_STAGE_BYTES;
+  // the ONLY LDS object of the kernel (a second one makes hipcc wait for every LDS-DMA before each ds_read):
+  // stage s: A at s * 2 SB, B at s * 2 SB + SB; after the loop the first word doubles as the "last arriver" flag
+  __shared__ __attribute__((aligned(1024))) char smem[4 * SB];
 
   // XCD-aware, bijective remap of the launch index (cdna_hip_programming.md T1)
   int L;
@@ -165,91 +211,259 @@ __global__ __launch_bounds__(GEMM_THREADS, MINW) void gemm_kernel(GemmParams<TI,
     const int b = blockIdx.x, q = p.n_wg / 8, r = p.n_wg % 8, xcd = b % 8, idx = b / 8;
     L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int split = L / p.n_tiles;
-  const int packed = p.tile_map[L % p.n_tiles];
+  const int split = L / p.n_tiles, tile = L % p.n_tiles;
+  const int packed = p.tile_map[tile];
   const int bm = packed >> 16, bn = packed & 0xffff;
   const int bm0 = bm * GEMM_BM, bn0 = bn * GEMM_BN;
   const int kbeg = split * p.k_chunk;
   const int kend = min(p.K, kbeg + p.k_chunk);
-  TO* __restrict__ C = p.C + (int64_t)split * p.split_stride;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = (wave >> 2) * 64, wn = (wave & 3) * 32;
-  const int l15 = lane & 15, l4 = lane >> 4;
+  // Nothing derived from the lane index has to stay in a register across the main loop except the two fragment addresses
+  // and the four DMA offsets: the f32 build has 64 + 128 accumulator registers and no room for bystanders, so the lane
+  // index is produced again (v_mbcnt, opaque to the optimiser) behind the loop.
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  int lane = gemm_lane_id();
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
 
-  acc_t acc[4][2];
-  d4_t wide[WIDE ? 4 : 1][WIDE ? 2 : 1];
+  acc_t acc[4][4];
+  acc_t wide[WIDE ? 4 : 1][WIDE ? 4 : 1];      // second-level f32 sums (see GEMM_FLUSH_PRODUCTS)
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < 4; ++j) {
       acc[i][j] = acc_t{0, 0, 0, 0};
-      if constexpr (WIDE) wide[i][j] = d4_t{0, 0, 0, 0};
+      if constexpr (WIDE) wide[i][j] = acc_t{0, 0, 0, 0};
     }
 
-  // workgroup-uniform: whole tile inside the matrices and both operands 16-byte aligned -> unpredicated vector loads
-  const bool interior = (bm0 + GEMM_BM <= p.M) && (bn0 + GEMM_BN <= p.N) && p.vec_a && p.vec_b;
-  const TI* __restrict__ baseA = A_KFAST ? p.A + (int64_t)bm0 * p.lda : p.A + bm0;   // + k offset per tile
-  const TI* __restrict__ baseB = B_NFAST ? p.B + bn0 : p.B + (int64_t)bn0 * p.ldb;
-  const int64_t kstepA = A_KFAST ? 1 : p.lda, kstepB = B_NFAST ? p.ldb : 1;
-  TI ra[8], rb[8];
-  auto load = [&](int k0) {
-    if (interior && k0 + GEMM_BK <= kend) {
-      IOA::load_fast(baseA + (int64_t)k0 * kstepA, p.lda, ra);
-      IOB::load_fast(baseB + (int64_t)k0 * kstepB, p.ldb, rb);
-    } else {
-      IOA::load_slow(p.A, p.lda, bm0, p.M, k0, kend, ra);
-      IOB::load_slow(p.B, p.ldb, bn0, p.N, k0, kend, rb);
+  // ---- staging ----
+  // fast path (LDS-DMA): wave w issues the instructions q = 4 w + j (j = 0..3) of each operand; instruction q fills the
+  // LDS bytes [q * 1024, q * 1024 + 1024) of the stage, lane l the 16 bytes at q * 1024 + 16 l
+  const char* tileA = reinterpret_cast<const char*>(A_KFAST ? p.A + (int64_t)bm0 * p.lda : p.A + bm0);   // + k offset per tile
+  const char* tileB = reinterpret_cast<const char*>(B_NFAST ? p.B + bn0 : p.B + (int64_t)bn0 * p.ldb);
+  const int64_t kstepA = (A_KFAST ? 1 : p.lda) * E, kstepB = (B_NFAST ? p.ldb : 1) * E;
+  uint32_t va[2], vb[2];
+#pragma unroll
+  for (int jp = 0; jp < 2; ++jp) {
+    va[jp] = OA::voff(lane, jp, p.lda);
+    vb[jp] = OB::voff(lane, jp, p.ldb);
+  }
+  const bool fast = p.vec_a && p.vec_b;
+  // buffer form of the LDS-DMA: descriptor base = tile origin + k offset and range = what is left of the operand
+  // (scalars), 32-bit lane offsets, scalar offsets for the four instructions of a wave
+  using lptr_t = __attribute__((address_space(3))) void*;
+  auto stage_fast = [&](int k0, int s) {
+#if defined(__HIP_DEVICE_COMPILE__)   // (the host pass has no buffer-descriptor type and would drop the kernel's launch stub)
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(tileA + (int64_t)k0 * kstepA), 0,
+                                                                       (int)OA::remaining(p.M, bm0, p.K, k0, p.lda), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(tileB + (int64_t)k0 * kstepB), 0,
+                                                                       (int)OB::remaining(p.N, bn0, p.K, k0, p.ldb), 0x00020000);
+    char* la = smem + s * 2 * SB + wave * 4096;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(la + j * 1024), 16, va[j & 1], OA::soff(wave, j, p.lda), 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lptr_t)(la + SB + j * 1024), 16, vb[j & 1], OB::soff(wave, j, p.ldb), 0, 0);
+#endif
+  };
+  // slow path: predicated element loads, zero filled, into the same image
+  auto stage_slow = [&](int k0, int s, int tid) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int o = (tid + GEMM_THREADS * j) * 16;
+      int r, k;
+      vec_t x;
+      OA::where(o, r, k);
+#pragma unroll
+      for (int e = 0; e < CE; ++e) {
+        const int er = bm0 + (A_KFAST ? r : r + e), ek = k0 + (A_KFAST ? k + e : k);
+        TI v = TI(0);
+        if (er < p.M && ek < kend) v = A_KFAST ? p.A[(int64_t)er * p.lda + ek] : p.A[(int64_t)ek * p.lda + er];
+        x[e] = v;
+      }
+      *reinterpret_cast<vec_t*>(smem + s * 2 * SB + o) = x;
+      OB::where(o, r, k);
+#pragma unroll
+      for (int e = 0; e < CE; ++e) {
+        const int er = bn0 + (!B_NFAST ? r : r + e), ek = k0 + (!B_NFAST ? k + e : k);
+        TI v = TI(0);
+        if (er < p.N && ek < kend) v = !B_NFAST ? p.B[(int64_t)er * p.ldb + ek] : p.B[(int64_t)ek * p.ldb + er];
+        x[e] = v;
+      }
+      *reinterpret_cast<vec_t*>(smem + s * 2 * SB + SB + o) = x;
     }
   };
-  const int nkt = (kend - kbeg + GEMM_BK - 1) / GEMM_BK;
-  if (nkt > 0) load(kbeg);
-  for (int kt = 0; kt < nkt; ++kt) {
-    IOA::store(As, ra);
-    IOB::store(Bs, rb);
-    __syncthreads();
-    if (kt + 1 < nkt) load(kbeg + (kt + 1) * GEMM_BK);
+  int fa0 = OA::frag_base(wm, lane), fb0 = OB::frag_base(wn, lane) + SB;
+  frag_t af[2][4], bf[2][4];
+  auto read_frags = [&](const char* sb, int q, frag_t (&a)[4], frag_t (&b)[4]) {
+    // (the per-phase XORs of the two base addresses are one instruction each; hoisted out of the loop they would occupy
+    // up to six more registers for its whole duration - the empty asm makes the bases look freshly written)
+#ifndef GEMM_NO_LAUNDER
+    asm("" : "+v"(fa0), "+v"(fb0));
+#endif
 #pragma unroll
-    for (int k4 = 0; k4 < GEMM_BK / 4; ++k4) {
-      const int kr = k4 * 4 + l4;
-      TI a[4], b[2];
+    for (int f = 0; f < 4; ++f) {
+      a[f] = *reinterpret_cast<const frag_t*>(sb + OA::frag_addr(fa0, q, f));
+      b[f] = *reinterpret_cast<const frag_t*>(sb + OB::frag_addr(fb0, q, f));
+    }
+  };
+  auto mfmas = [&](const frag_t (&a)[4], const frag_t (&b)[4]) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = As[kr][wm + i * 16 + l15];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = Bs[kr][wn + j * 16 + l15];
+    for (int e = 0; e < 2; ++e)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = M_::mma(a[i], b[j], acc[i][j]);
-    }
+        for (int j = 0; j < 4; ++j) acc[i][j] = M_::mma(OA::value(a, e, i), OB::value(b, e, j), acc[i][j]);
+  };
+
+  const int nkt = (kend - kbeg + BK - 1) / BK;
+  // complete k-tiles go through the pipelined LDS-DMA loop.  The DMA needs no alignment beyond the element's (measured:
+  // odd leading dimensions and odd bases run at the same rate).  A row-fast operand whose row count is not a multiple of
+  // the chunk has chunks that straddle its last row: in the LAST k-row of the matrix such a chunk would leave the operand,
+  // so the k-tile holding that row takes the register path below.
+  const bool ragged = (!A_KFAST && (p.M % CE) != 0) || (B_NFAST && (p.N % CE) != 0);
+  int nfull = fast ? (kend - kbeg) / BK : 0;
+  if (ragged && kend == p.K && nfull > 0 && nfull * BK == kend - kbeg) --nfull;
+  constexpr int FLUSH_TILES = GEMM_FLUSH_PRODUCTS / BK;
+  auto flush = [&](int kt) {
     if constexpr (WIDE) {
-      if ((kt % GEMM_FLUSH_TILES) == GEMM_FLUSH_TILES - 1) {
+      if ((kt % FLUSH_TILES) == FLUSH_TILES - 1) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
+          for (int j = 0; j < 4; ++j) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) wide[i][j][r] += (double)acc[i][j][r];
+            for (int r = 0; r < 4; ++r) wide[i][j][r] += acc[i][j][r];
             acc[i][j] = acc_t{0, 0, 0, 0};
           }
       }
     }
-    __syncthreads();   // every wave is done with this k-tile before it is overwritten
+  };
+  if (nfull > 0) {
+    stage_fast(kbeg, 0);
+    __syncthreads();
+    if (nfull > 1) stage_fast(kbeg + BK, 1);
+    read_frags(smem, 0, af[0], bf[0]);
+  }
+  for (int kt = 0; kt < nfull; ++kt) {
+    const char* sb = smem + (kt & 1) * 2 * SB;
+#pragma unroll
+    for (int q = 0; q < NPH; ++q) {
+      if (q + 1 < NPH) {
+        read_frags(sb, q + 1, af[(q + 1) & 1], bf[(q + 1) & 1]);
+      } else if (kt + 1 < nfull) {
+        // every read of k-tile kt has been issued; behind this barrier they have all completed in every wave and
+        // k-tile kt + 1 has landed (vmcnt(0) of the DMA issued one tile ago)
+        __syncthreads();
+#if !defined(GEMM_ABLATE) || GEMM_ABLATE != 1
+        if (kt + 2 < nfull) stage_fast(kbeg + (kt + 2) * BK, kt & 1);
+#endif
+        read_frags(smem + ((kt + 1) & 1) * 2 * SB, 0, af[0], bf[0]);
+      }
+      mfmas(af[q & 1], bf[q & 1]);
+    }
+    flush(kt);
+  }
+  lane = gemm_lane_id();
+  const int tid = wave * 64 + lane;
+  // the partial last k-tile, and every k-tile of unaligned operands: staged through registers, two barriers per tile
+  for (int kt = nfull; kt < nkt; ++kt) {
+    __syncthreads();
+    stage_slow(kbeg + kt * BK, 0, tid);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NPH; ++q) {
+      read_frags(smem, q, af[0], bf[0]);
+      mfmas(af[0], bf[0]);
+    }
+    flush(kt);
   }
 
-  const bool offdiag = (bm != bn);
+  // ---- totals of this slice as doubles ----
+  d4_t tot[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = bm0 + wm + i * 16 + M_::row(lane, r);
-        const int col = bn0 + wn + j * 16 + l15;
+        double v = (double)acc[i][j][r];
+        if constexpr (WIDE) v += (double)wide[i][j][r];
+        tot[i][j][r] = v;
+      }
+
+  if (p.splits > 1) {
+    // publish this slice's sums in register order - element pair (i, j, h) of thread tid at ((i * 4 + j) * 2 + h) * 256 + tid,
+    // 1 KB per store instruction - with write-through (sc1) 16-byte stores: no release fence (the L2 write-back of a fence
+    // costs microseconds with 128 KB freshly dirtied per workgroup: MI355X_MICROARCH.md "publish-large"), the drained
+    // stores + barrier + relaxed ticket are the publication (cdna_hip_programming.md 5, sc1 form of the split-K hand-off)
+    double* __restrict__ mine = p.slabs + ((size_t)split * p.n_tiles + tile) * (size_t)(GEMM_BM * GEMM_BN);
+#if defined(__HIP_DEVICE_COMPILE__)
+    {
+      typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(mine, 0, GEMM_BM * GEMM_BN * 8, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const d2_t v{tot[i][j][2 * h], tot[i][j][2 * h + 1]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rs, tid * 16, ((i * 4 + j) * 2 + h) * 4096, /*sc1*/ 16);
+          }
+    }
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                      // also: every wave is done with the LDS stages
+    int* flag = reinterpret_cast<int*>(smem);
+    if (tid == 0) {
+      const int ticket = __hip_atomic_fetch_add(p.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = ticket == p.splits - 1;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(p.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+      }
+      *flag = last;
+    }
+    __syncthreads();
+    if (*flag == 0) return;
+    // the last arriver: slabs of all slices in slice order (its own comes back from memory too: same bits for every
+    // arrival order)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tot[i][j] = d4_t{0, 0, 0, 0};
+    for (int z = 0; z < p.splits; ++z) {
+      const d2_t* __restrict__ sl = reinterpret_cast<const d2_t*>(p.slabs + ((size_t)z * p.n_tiles + tile) * (size_t)(GEMM_BM * GEMM_BN));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const d2_t v = sl[((i * 4 + j) * 2 + h) * GEMM_THREADS + tid];
+            tot[i][j][2 * h] += v[0];
+            tot[i][j][2 * h + 1] += v[1];
+          }
+        asm volatile("" ::: "memory");     // eight loads in flight per lane, not thirty-two: the totals already take 128 registers
+      }
+    }
+  }
+
+  // ---- epilogue ----
+  const bool offdiag = (bm != bn);
+  const int l15 = lane & 15;
+  TO* __restrict__ C = p.C;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = bm0 + wm + OA::index(i, M_::row(lane, r));
+        const int col = bn0 + wn + OB::index(j, l15);
         if (row < p.M && col < p.N) {
-          double v = (double)acc[i][j][r];
-          if constexpr (WIDE) v += wide[i][j][r];
-          v *= p.alpha;
+          double v = tot[i][j][r] * p.alpha;
           if (p.row_scale) v *= p.row_scale[row];
           if (p.col_scale) v *= p.col_scale[col];
           const int64_t o = (int64_t)row * p.ldc + col;
@@ -258,28 +472,6 @@ __global__ __launch_bounds__(GEMM_THREADS, MINW) void gemm_kernel(GemmParams<TI,
           if (p.mirror != 0 && offdiag) C[(int64_t)col * p.ldc + row] = (TO)(p.mirror > 0 ? v : -v);
         }
       }
-}
-
-// C = alpha * rs*cs * sum_z W[z] + beta*C, honouring upper_only / mirror at the GEMM's block-tile granularity
-template <typename TO>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const double* __restrict__ W, int splits, int64_t split_stride,
-                                                            TO* __restrict__ C, int M, int N, int64_t ldc, double alpha,
-                                                            double beta, const double* __restrict__ row_scale,
-                                                            const double* __restrict__ col_scale, int upper_only, int mirror) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)M * N) return;
-  const int m = (int)(idx / N), n = (int)(idx % N);
-  const int tm = m / GEMM_BM, tn = n / GEMM_BN;
-  if (upper_only && tn < tm) return;
-  double v = 0.0;
-  for (int z = 0; z < splits; ++z) v += W[(int64_t)z * split_stride + idx];
-  v *= alpha;
-  if (row_scale) v *= row_scale[m];
-  if (col_scale) v *= col_scale[n];
-  const int64_t o = (int64_t)m * ldc + n;
-  if (beta != 0.0) v += beta * (double)C[o];
-  C[o] = (TO)v;
-  if (mirror != 0 && tn > tm) C[(int64_t)n * ldc + m] = (TO)(mirror > 0 ? v : -v);
 }
 
 struct GemmOpts {
@@ -294,67 +486,83 @@ struct GemmOpts {
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;   // optional: recorded around the MFMA kernel launch alone
 };
 
-// stream-K schedule state of the NT kernel (gemm_nt.h)
-struct GemmNtWorkspace {
-  DevBuf<double> partial;       // raw sums of the partial segments, [grid][2][BM * BN]
-  DevBuf<int> split_tiles;      // tiles whose units span more than one workgroup range
-  int n_split = 0;
-  int64_t key_tiles = -1;
-  int key_nkt = -1, key_upw = -1;
-  int n_cus = 0;
-};
-
-// scratch for split-K partial sums and the tile-order tables, owned by the caller (one per stream)
+// scratch for split-K slabs / tickets and the tile-order tables, owned by the caller (one per stream)
 struct GemmWorkspace {
-  DevBuf<double> partial;
-  GemmNtWorkspace nt;
-  struct Map { int tm, tn, upper, ratio; DevBuf<int> dev; int n; };
+  DevBuf<double> slabs;
+  DevBuf<int> counters;
+  size_t counters_ready = 0;     // leading counters known to be zero
+  struct Map { int tm, tn, upper; DevBuf<int> dev; int n; };
   std::vector<std::unique_ptr<Map>> maps;
+  int n_cus = 0;
 
   // Tiles are enumerated in 8 x 8 super-blocks: the ~64 workgroups that share one XCD's L2 at a time then touch only
   // 8 + 8 operand panels, so each panel slice is fetched from HBM / Infinity Cache once per XCD and reused from L2.
-  // `ratio` = tile rows / tile columns (rectangular tiles of gemm_big.h): with `upper`, tile (i, j) is kept when it reaches
-  // the diagonal or lies above it, j >= ratio * i.
-  const Map& tile_map(hipStream_t st, int tm, int tn, bool upper, int ratio = 1) {
+  const Map& tile_map(hipStream_t st, int tm, int tn, bool upper) {
     for (auto& m : maps)
-      if (m->tm == tm && m->tn == tn && m->upper == (int)upper && m->ratio == ratio) return *m;
+      if (m->tm == tm && m->tn == tn && m->upper == (int)upper) return *m;
     constexpr int G = 8;
     std::vector<int> order;
     for (int si = 0; si < tm; si += G)
-      for (int sj = upper ? (si * ratio) / G * G : 0; sj < tn; sj += G)
+      for (int sj = upper ? si : 0; sj < tn; sj += G)
         for (int i = si; i < std::min(si + G, tm); ++i)
           for (int j = sj; j < std::min(sj + G, tn); ++j)
-            if (!upper || j >= ratio * i) order.push_back((i << 16) | j);
+            if (!upper || j >= i) order.push_back((i << 16) | j);
     auto m = std::make_unique<Map>();
-    m->tm = tm; m->tn = tn; m->upper = upper; m->ratio = ratio; m->n = (int)order.size();
+    m->tm = tm; m->tn = tn; m->upper = upper; m->n = (int)order.size();
     XMCA_HIP(hipMemcpyAsync(m->dev.ensure(order.size()), order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice, st));
     XMCA_HIP(hipStreamSynchronize(st));
     maps.push_back(std::move(m));
     return *maps.back();
+  }
+  int* tickets(hipStream_t st, size_t n) {
+    if (n > counters_ready) {
+      const size_t want = std::max<size_t>(n, 4096);
+      int* c = counters.ensure(want);
+      XMCA_HIP(hipMemsetAsync(c, 0, sizeof(int) * counters.cap, st));
+      counters_ready = counters.cap;
+    }
+    return counters.get();
+  }
+  int cus() {
+    if (n_cus == 0) {
+      int dev = 0, n = 256;
+      (void)hipGetDevice(&dev);
+      (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+      n_cus = n > 0 ? n : 256;
+    }
+    return n_cus;
   }
 };
 
 template <typename TI, typename TO, bool WIDE>
 static void launch_gemm_variant(hipStream_t st, const GemmParams<TI, TO>& p, bool a_kfast, bool b_nfast) {
   dim3 grid(p.n_wg), block(GEMM_THREADS);
-  static const int minw = [] { const char* e = std::getenv("XMCA_GEMM_MINW"); return (e && e[0] == '2') ? 2 : 4; }();
-  if (minw == 4) {
-    if (a_kfast && b_nfast) hipLaunchKernelGGL((gemm_kernel<TI, TO, true, true, WIDE, 4>), grid, block, 0, st, p);
-    else if (a_kfast && !b_nfast) hipLaunchKernelGGL((gemm_kernel<TI, TO, true, false, WIDE, 4>), grid, block, 0, st, p);
-    else if (!a_kfast && b_nfast) hipLaunchKernelGGL((gemm_kernel<TI, TO, false, true, WIDE, 4>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((gemm_kernel<TI, TO, false, false, WIDE, 4>), grid, block, 0, st, p);
-  } else {
-    if (a_kfast && b_nfast) hipLaunchKernelGGL((gemm_kernel<TI, TO, true, true, WIDE, 2>), grid, block, 0, st, p);
-    else if (a_kfast && !b_nfast) hipLaunchKernelGGL((gemm_kernel<TI, TO, true, false, WIDE, 2>), grid, block, 0, st, p);
-    else if (!a_kfast && b_nfast) hipLaunchKernelGGL((gemm_kernel<TI, TO, false, true, WIDE, 2>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((gemm_kernel<TI, TO, false, false, WIDE, 2>), grid, block, 0, st, p);
-  }
+  if (a_kfast && b_nfast) hipLaunchKernelGGL((gemm_kernel<TI, TO, true, true, WIDE>), grid, block, 0, st, p);
+  else if (a_kfast && !b_nfast) hipLaunchKernelGGL((gemm_kernel<TI, TO, true, false, WIDE>), grid, block, 0, st, p);
+  else if (!a_kfast && b_nfast) hipLaunchKernelGGL((gemm_kernel<TI, TO, false, true, WIDE>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((gemm_kernel<TI, TO, false, false, WIDE>), grid, block, 0, st, p);
   XMCA_HIP(hipGetLastError());
 }
 
-}  // namespace xmca
-#include "gemm_nt.h"
-namespace xmca {
+// number of k-slices.  Cost model in units of one k-tile of a workgroup that has its CU to itself, fitted to sweeps of the
+// split count on the shapes of the path (scripts/probes/gemm_probe.cpp sweep; profiles/r04_gemm_split_sweep.txt): a
+// workgroup alone on a CU runs at ~0.75 of the matrix rate, two sharing one at ~0.87 together (1.73 units per k-tile
+// each).  The workgroups of a launch all take the same time, so they run in rounds of 2 x CUs: full rounds at 1.73, a last
+// round that fills at most half of the slots at 1 (one workgroup per CU).  8 units of prologue / epilogue / slab traffic
+// per workgroup, one per slab the last arriver adds up, and half a percent per slice against ties.
+static inline int gemm_choose_splits(int64_t tiles, int nkt, int n_cus) {
+  const int max_s = std::min(std::max(nkt / 4, 1), 128);
+  int best_s = 1;
+  double best = 1e300;
+  for (int s = 1; s <= max_s; ++s) {
+    const double q = (double)tiles * s / (2.0 * n_cus);
+    const double fl = std::floor(q), phi = q - fl;
+    const double rounds = fl * 1.73 + (phi < 1e-9 ? 0.0 : (phi <= 0.5 ? 1.0 : 1.73));
+    const double cost = ((double)nkt / s + 8.0) * rounds * (1.0 + 0.005 * s) + (s > 1 ? (double)s : 0.0);
+    if (cost < best) { best = cost; best_s = s; }
+  }
+  return best_s;
+}
 
 // TI in {float,double}; TO in {float,double}.  f32 operands always use WIDE accumulation.
 template <typename TI, typename TO>
@@ -362,56 +570,37 @@ void gemm(hipStream_t st, GemmWorkspace& ws, const TI* A, int64_t lda, const TI*
           int N, int K, const GemmOpts& o) {
   if (M <= 0 || N <= 0) return;
   XMCA_CHECK(!o.upper_only || M == N, XMCA_ERR_INVALID, "gemm: upper_only needs a square result");
-  // both operands contiguous along the contraction axis (covariance / Gram products): stream-K kernel of gemm_nt.h
-  if (o.a_kfast && !o.b_nfast && gemm_nt<TI, TO>(st, ws, ws.nt, A, lda, B, ldb, C, ldc, M, N, K, o)) return;
+  constexpr int BK = GemmK<TI>::BK, CE = GemmK<TI>::CE;
   const int tm = ceil_div(M, GEMM_BM), tn = ceil_div(N, GEMM_BN);
   const int64_t tiles = o.upper_only ? (int64_t)tm * (tm + 1) / 2 : (int64_t)tm * tn;
-  const int nkt = ceil_div(K, GEMM_BK);
-  int splits = o.force_splits;
-  if (splits <= 0) {
-    // Cost model in units of one k-tile of one workgroup (two workgroups share a CU -> 512 slots), fitted to a sweep of
-    // the split count on the C2 Gram shape (scripts/gram_splits.py: 3 -> 2.13 ms, 5 -> 1.85, 7 -> 1.74, 9 -> 1.72,
-    // 14 -> 1.79):  (tiles * s / 512 + 1/2) rounds - the last, partly filled round costs about half a round because its
-    // workgroups meet less contention - times (k-tiles per slice + ~3 tiles of prologue/epilogue), plus the partial-sum
-    // traffic of s slices.
-    splits = 1;
-    if (nkt >= 32) {
-      const int max_s = std::min(std::max(nkt / 8, 1), 128);
-      const int min_s = std::min(ceil_div(nkt, 512), max_s);
-      double best = 1e300;
-      for (int s_ = std::max(min_s, 1); s_ <= max_s; ++s_) {
-        const double rounds = std::max((double)tiles * s_ / 512.0, 1.0) + 0.5;
-        const double cost = rounds * ((double)nkt / s_ + 3.0) + (s_ > 1 ? s_ * (double)tiles / 200.0 : 0.0);
-        if (cost < best) { best = cost; splits = s_; }
-      }
-    }
-  }
+  const int nkt = ceil_div(K, BK);
+  constexpr bool WIDE = std::is_same<TI, float>::value;
+  int splits = o.force_splits > 0 ? o.force_splits : gemm_choose_splits(tiles, nkt, ws.cus());
+  if (WIDE) splits = std::max(splits, ceil_div(K, GEMM_SLICE_PRODUCTS));
   const GemmWorkspace::Map& map = ws.tile_map(st, tm, tn, o.upper_only);
   XMCA_CHECK(map.n == tiles && tm < 65536 && tn < 65536, XMCA_ERR_INVALID, "gemm: tile map mismatch");
-  constexpr bool WIDE = std::is_same<TI, float>::value;
-  constexpr int VW = Mfma<TI>::VW;
-  const int vec_a = (lda % VW == 0) && (reinterpret_cast<uintptr_t>(A) % 16 == 0);
-  const int vec_b = (ldb % VW == 0) && (reinterpret_cast<uintptr_t>(B) % 16 == 0);
-  if (splits <= 1 || K == 0) {
-    GemmParams<TI, TO> p{A, B, C, M, N, K, lda, ldb, ldc, o.alpha, o.beta, o.row_scale, o.col_scale,
-                         o.upper_only ? 1 : 0, o.mirror, K > 0 ? K : 1, 0, (int)tiles, (int)tiles, map.dev.get(), vec_a, vec_b};
-    if (o.ev_begin) XMCA_HIP(hipEventRecord(o.ev_begin, st));
-    launch_gemm_variant<TI, TO, WIDE>(st, p, o.a_kfast, o.b_nfast);
-    if (o.ev_end) XMCA_HIP(hipEventRecord(o.ev_end, st));
-    return;
+  // LDS-DMA: tile-relative byte offsets must fit 32 bits, elements naturally aligned (anything else: register path)
+  const int vec_a = lda * (int64_t)sizeof(TI) * 128 < ((int64_t)1 << 32) && reinterpret_cast<uintptr_t>(A) % sizeof(TI) == 0;
+  const int vec_b = ldb * (int64_t)sizeof(TI) * 128 < ((int64_t)1 << 32) && reinterpret_cast<uintptr_t>(B) % sizeof(TI) == 0;
+  int k_chunk = K > 0 ? K : 1;
+  if (splits > 1) {
+    k_chunk = ceil_div(nkt, splits) * BK;
+    if (WIDE) k_chunk = std::min(k_chunk, GEMM_SLICE_PRODUCTS);
+    splits = ceil_div(K, k_chunk);
   }
-  int k_chunk = ceil_div(nkt, splits) * GEMM_BK;
-  splits = ceil_div(K, k_chunk);
-  const int64_t stride = (int64_t)M * N;
-  double* W = ws.partial.ensure((size_t)stride * splits);
-  GemmParams<TI, double> p{A, B, W, M, N, K, lda, ldb, (int64_t)N, 1.0, 0.0, nullptr, nullptr,
-                           o.upper_only ? 1 : 0, 0, k_chunk, stride, (int)tiles, (int)(tiles * splits), map.dev.get(), vec_a, vec_b};
+  if (splits < 1 || K <= 0) splits = 1;
+  XMCA_CHECK(tiles * splits < (int64_t)1 << 31, XMCA_ERR_INVALID, "gemm: too many workgroups");
+  double* slabs = nullptr;
+  int* counters = nullptr;
+  if (splits > 1) {
+    slabs = ws.slabs.ensure((size_t)splits * tiles * GEMM_BM * GEMM_BN);
+    counters = ws.tickets(st, (size_t)tiles);
+  }
+  GemmParams<TI, TO> p{A, B, C, M, N, K, lda, ldb, ldc, o.alpha, o.beta, o.row_scale, o.col_scale, o.upper_only ? 1 : 0, o.mirror,
+                       k_chunk, splits, (int)tiles, (int)(tiles * splits), map.dev.get(), vec_a, vec_b, slabs, counters};
   if (o.ev_begin) XMCA_HIP(hipEventRecord(o.ev_begin, st));
-  launch_gemm_variant<TI, double, WIDE>(st, p, o.a_kfast, o.b_nfast);
+  launch_gemm_variant<TI, TO, WIDE>(st, p, o.a_kfast, o.b_nfast);
   if (o.ev_end) XMCA_HIP(hipEventRecord(o.ev_end, st));
-  hipLaunchKernelGGL((splitk_reduce_kernel<TO>), dim3((unsigned)((stride + 255) / 256)), dim3(256), 0, st, W, splits, stride, C,
-                     M, N, ldc, o.alpha, o.beta, o.row_scale, o.col_scale, o.upper_only ? 1 : 0, o.mirror);
-  XMCA_HIP(hipGetLastError());
 }
 
 }  // namespace xmca
