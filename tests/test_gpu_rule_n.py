@@ -43,13 +43,20 @@ def _oracle_run(hip, T, widths, seed, run, cplx, rot):
     (60, (300, 200), False, (5, 3)),        # rotated: Promax
     (60, (200, 150), True, (4, 2)),         # rotated complex
     (40, (24,), False, (4, 1)),             # rotated EOF
+    # eigenproblems of 192 rows and more: the tridiagonal values-only route that every C4 surrogate takes
+    # (values_by_cholesky -> trd_step_kernel / trd_resident_kernel -> trd_bisect_kernel)
+    (500, (1200, 900), True, None),         # m = 251 complex: one launch per column
+    (900, (2200, 1700), True, None),        # m = 451 complex: the persistent reduction, tagged exchange
+    (800, (2000,), False, None),            # EOF, n = 800 real
+    (640, (1500, 1100), False, None),       # real two-field model, n = 640
 ])
 def test_rule_n_runs_equal_the_oracle_on_the_same_normals(hip, T, widths, cplx, rot):
-    seed, n_runs = 20240607, 5
+    seed, n_runs = 20240607, (5 if T < 200 else 2)
     n_fields = len(widths)
     rank = min((T,) + widths)
     p, power = rot if rot else (0, 0)
     n_out = p if rot else rank
+    trd_before = hip.timings().get("trd_reduce_calls", 0)
     spectra, kept = hip.rule_n(T, widths[0], widths[1] if n_fields == 2 else 0, n_fields, cplx, bool(rot), p, max(power, 1), 1e-8,
                                0, n_runs, seed, np.float64, n_out)
     assert spectra.shape == (n_runs, n_out)
@@ -64,10 +71,50 @@ def test_rule_n_runs_equal_the_oracle_on_the_same_normals(hip, T, widths, cplx, 
         keep = ref > 1e-7 * ref[0]          # null modes (centering; the analytic signal keeps T/2 of them) carry rounding only
         assert np.max(np.abs(spectra[r][keep] - ref[keep]) / ref[keep]) < 1e-5, (r, widths, cplx, rot)
         assert np.all(np.abs(spectra[r][~keep]) < 1e-5 * ref[0])
+    if T >= 200:
+        assert hip.timings().get("trd_reduce_calls", 0) >= trd_before + n_runs        # ... and it is the route that ran
     # a later block of runs is keyed by the run index only
     again, _ = hip.rule_n(T, widths[0], widths[1] if n_fields == 2 else 0, n_fields, cplx, bool(rot), p, max(power, 1), 1e-8,
-                          3, 5, seed, np.float64, n_out)
-    assert np.array_equal(again, spectra[3:5])
+                          n_runs - 2, n_runs, seed, np.float64, n_out)
+    assert np.array_equal(again, spectra[n_runs - 2:n_runs])
+
+
+def test_numpy_generator_equals_the_device_generator(hip):
+    """oracle/philox_numpy.py restates philox_normal_kernel (Philox4x32-10 keyed (seed, run, side) + Box-Muller): the
+    integers are the same by construction, the normals to the last ulps of the two libms.  With it a surrogate exists
+    without a GPU - tests/golden/rule_n_c4_run0.npz is the REAL reference's spectrum of one."""
+    from oracle.philox_numpy import surrogate
+    for n, seed, run, side in [(1, 1, 0, 0), (1001, 1, 0, 1), (65536, 20240607, 3, 0), (300000, (1 << 40) + 12345, 7, 1)]:
+        dev = hip.surrogate(n, seed, run, side)
+        ref = surrogate(n, seed, run, side)
+        assert dev.shape == ref.shape
+        assert np.max(np.abs(dev - ref)) < 4e-15, (n, seed, run, side)
+    g = np.load(os.path.join(REPO, "tests", "golden", "rule_n_c4_run0.npz"))
+    T, (Nx, Ny), seed = int(g["T"]), [int(x) for x in g["widths"]], int(g["seed"])
+    assert np.max(np.abs(hip.surrogate(64, seed, 0, 0) - g["first_normals_left"])) < 4e-15         # the fields the reference saw
+    assert np.max(np.abs(hip.surrogate(64, seed, 0, 1) - g["first_normals_right"])) < 4e-15
+    assert abs(hip.surrogate(T * Nx, seed, 0, 0).sum() - float(g["checksum_left"])) < 1e-6
+
+
+def test_c4_surrogate_at_full_size_equals_the_reference(hip):
+    """BASELINE configs[3] at FULL size: surrogate (seed 1, run 0) of rule_n on T = 5000 x (20 000, 15 000), complexify -
+    the normals the device generates, restated in numpy (oracle/philox_numpy.py), went through the REAL reference
+    (xmca/array.py:1753-1765: MCA(*data).solve(complexify=True), 392 s on 8 cores; oracle/make_config_goldens.py c4_run0).
+    Row 0 of xmca_rule_n must be that spectrum: all 2500 non-null modes at 1e-5; the reference drops the rotated run
+    (Varimax does not converge on complex white noise, array.py:1762-1763) and so must the device."""
+    g = np.load(os.path.join(REPO, "tests", "golden", "rule_n_c4_run0.npz"))
+    T, (Nx, Ny), seed = int(g["T"]), [int(x) for x in g["widths"]], int(g["seed"])
+    ref = g["variance"]
+    trd_before = hip.timings().get("trd_reduce_calls", 0)
+    spectra, kept = hip.rule_n(T, Nx, Ny, 2, True, False, 0, 1, 1e-8, 0, 1, seed, np.float64, ref.size)
+    assert kept[0] == 1 and hip.timings().get("trd_reduce_calls", 0) == trd_before + 1
+    keep = ref > 1e-7 * ref[0]
+    assert keep.sum() == T // 2
+    assert np.max(np.abs(spectra[0][keep] - ref[keep]) / ref[keep]) < 1e-5
+    assert np.all(np.abs(spectra[0][~keep]) < 1e-5 * ref[0])
+    assert int(g["rotated_dropped"]) == 1
+    _, kept_rot = hip.rule_n(T, Nx, Ny, 2, True, True, 20, 4, 1e-8, 0, 1, seed, np.float64, 20)
+    assert kept_rot[0] == 0
 
 
 _DROP_CASE = dict(T=150, widths=(400, 300), seed=99, n_runs=8, rot=(30, 4))
@@ -259,11 +306,36 @@ def test_bench_py_launches_its_own_ranks():
     assert len(lines) == 1                                  # rank 0 only
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["rule_n"]["runs"] == 2 and line["rule_n"]["shape"] == [5000, 2]
-    assert line["rule_n"]["spectrum_sum_check"] < 1e-9 and line["roofline"]["kernel"].startswith("jacobi_fused_round_kernel")
+    # the gathered spectra are those of the runs 0, 1: run 0 is the surrogate the REAL reference solved (rule_n_c4_run0.npz)
+    assert line["rule_n"]["run0_vs_reference"]["max_rel_err_nonnull_modes"] < 1e-5 and line["rule_n"]["run0_vs_reference"]["modes"] == 2500
+    assert line["roofline"]["kernel"].startswith("jacobi_fused_round_kernel")      # (T = 400: below the tridiagonal route's 768 rows)
     # a launcher that started a different number of ranks than --gpus is an error, not a silent n_gpus = 1
     bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4", "--steps", "1"],
                          env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=REPO, capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr
+
+
+def test_bench_py_reports_the_tridiagonal_reduction_as_its_dominant_kernel():
+    """At a workload whose T x T eigenproblem takes the tridiagonal route with vectors (T >= 768) the `roofline` block of the
+    bench line must be the reduction kernel's - the branch the driver's full-size run takes - with the flop count of a
+    Householder tridiagonalisation, (4/3) T^3, and the bound it really has (one exchange per column: latency)."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    T = 800
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--T", str(T),
+                        "--N", "2400", "--no-cpu-baseline", "--no-e2e", "--no-rule-n"], env=env, cwd=REPO,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    rf = line["roofline"]
+    assert rf["kernel"].startswith("trd_") and rf["bound"] == "latency"
+    assert abs(rf["flops_per_launch"] - 4.0 / 3.0 * T ** 3) < 1.0
+    assert 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert rf["exchange_us_per_column"] > 0 and rf["launches_per_step"] >= 1
+    g = line["roofline_gemm"]
+    assert g["bound"] == "mfma" and 0 < g["frac"] < 1 and g["kernel"].startswith("gemm_kernel")
 
 
 def test_rule_n_spectra_do_not_depend_on_the_number_of_lanes():

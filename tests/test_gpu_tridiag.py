@@ -120,6 +120,53 @@ def test_hard_spectra_with_vectors(hip, monkeypatch, kind):
         assert hip.last_eigh_info["tridiag"] == 1
 
 
+def _glued_wilkinson(blocks, glue):
+    """`blocks` copies of the Wilkinson matrix W21+ (diagonal |i - 10|, off-diagonal 1) glued by off-diagonal entries
+    `glue`: its large eigenvalues come in pairs that agree to ~glue^2 / gap or much closer (the classic stress test of
+    inverse-iteration / MRRR eigenvectors; Dhillon, Parlett & Voemel 2005)."""
+    n = 21 * blocks
+    d = np.tile(np.abs(np.arange(21) - 10.0), blocks)
+    e = np.ones(n - 1)
+    e[20::21] = glue
+    return np.diag(d) + np.diag(e, 1) + np.diag(e, -1)
+
+
+@pytest.mark.parametrize("kind", ["wilkinson_1e-5", "wilkinson_1e-7", "pairs_1e-10", "pairs_1e-12", "pairs_1e-14", "mixed_gaps"])
+def test_near_degenerate_spectra_with_vectors(hip, monkeypatch, kind):
+    """Between `well separated` (twisted vectors + one Newton-Schulz step) and `repeated` (max |Z^H Z - I| > 0.3 -> Jacobi) lie
+    eigenvalue pairs with gaps of 1e-10 ... 1e-14 ||T||: twisted vectors of such a pair are nearly parallel, the clean-up
+    either repairs them or the solver must hand over.  Whichever route ends up handling the matrix (both are accepted), the
+    result has to be a full orthonormal decomposition - checked here at 1e-10, with the eigenvalues at 1e-12 ||A||."""
+    monkeypatch.setenv("XMCA_TRIDIAG_VEC_MIN_N", "2")
+    rng = np.random.default_rng(11)
+    if kind.startswith("wilkinson"):
+        T = _glued_wilkinson(30, float(kind.split("_")[1]))                 # n = 630, pairs glued at 1e-5 / 1e-7
+        n = T.shape[0]
+        Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        G = Q @ T @ Q.T                                                      # dense: the reduction has to find the structure again
+    else:
+        n = 640
+        lam = np.sort(rng.uniform(1.0, 2.0, n // 2))[::-1]
+        if kind == "mixed_gaps":
+            gaps = 10.0 ** rng.uniform(-15, -6, n // 2)
+        else:
+            gaps = np.full(n // 2, float(kind.split("_")[1]))
+        lam = np.r_[lam, lam * (1.0 - gaps)]                                 # every eigenvalue has a partner at relative distance `gap`
+        Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        G = (Q * lam) @ Q.T
+    G = (G + G.T) / 2
+    lam_d, U = hip.eigh(G)
+    ref = np.linalg.eigvalsh(G)[::-1]
+    sc = np.max(np.abs(ref))
+    assert np.max(np.abs(lam_d - ref)) < 1e-12 * sc
+    assert np.max(np.abs(U.T @ U - np.eye(n))) < 1e-10, hip.last_eigh_info
+    assert np.max(np.linalg.norm(G @ U - U * lam_d, axis=0)) < 1e-10 * sc
+    # values only: the same eigenvalues without the vector machinery
+    monkeypatch.setenv("XMCA_TRIDIAG_MIN_N", "2")
+    lam_v, _ = hip.eigh(G, vectors=False)
+    assert np.max(np.abs(lam_v - ref)) < 1e-12 * sc
+
+
 def test_nan_input_raises_like_gesdd(hip, monkeypatch):
     monkeypatch.setenv("XMCA_TRIDIAG_MIN_N", "2")
     G = _gram(300, False)
