@@ -41,7 +41,7 @@ typedef struct xmca_handle xmca_handle;
 /* library / device management ------------------------------------------------------------------------- */
 const char* xmca_version(void);
 /* Number of this header's ABI (XMCA_ABI_VERSION): the binding refuses a library built from another revision. */
-#define XMCA_ABI_VERSION 6
+#define XMCA_ABI_VERSION 7
 int xmca_abi_version(void);
 int xmca_device_count(void);
 int xmca_create(int device, xmca_handle** out);
@@ -133,6 +133,11 @@ int xmca_bootstrap_run(xmca_handle* h, const double* hilbert_col, const int64_t*
 int xmca_bootstrap_runs(xmca_handle* h, const double* hilbert_col, const int64_t* idx_left, const int64_t* idx_right, int64_t n_runs,
                         int rotated, int p, int power, double tol, double* spectra_out, int* kept_out, int64_t n_out);
 int xmca_is_complex(xmca_handle* h);
+/* 1 when the singular vectors of `side` from the last xmca_solve are resident in float32: a real float32 field decomposed on
+ * its dual side (N > T) keeps `_V` in the input's dtype as the reference does (xmca/array.py:584, the dtype of
+ * `VLT.conjugate().T`), and xmca_rotate_solved then multiplies float32 vectors by float32 sqrt(singular values) like the
+ * reference's host code (array.py:818-822).  Every other result is float64 planes. */
+int xmca_vectors_are_f32(xmca_handle* h, int side);
 /* Diagnostics of the last solve: for each of the up to three eigen-decompositions (left Gram, right Gram, kernel):
  * info[3*i + 0] = outer sweeps, info[3*i + 1] = tile size, info[3*i + 2] = pair slots (i = 0..2), then
  * info[9 + i]: bit 0 = the eigensolver inserted a Cholesky LR step (graded spectrum), bit 1 = the problem was solved by

@@ -10,12 +10,15 @@ X = gen_C()
 h = _hip.Handle(0)
 out = {}
 t0 = time.perf_counter(); m = MCA(X, handle=h, preprocess='device'); out["ctor_s"] = time.perf_counter() - t0
-t0 = time.perf_counter(); m.solve(); out["first_solve_s"] = time.perf_counter() - t0      # (pays the hipMalloc of the 10 GB result)
+t0 = time.perf_counter(); m.solve(); out["first_solve_s"] = time.perf_counter() - t0      # (pays the hipMalloc of the 5 GB float32 result)
 out["first_solve_stages_ms"] = h.timings()
 h.reset_timings()
 t0 = time.perf_counter(); m.solve(); out["solve_s"] = time.perf_counter() - t0
 out["stages_ms"] = h.timings()
+out["vectors_are_f32"] = bool(h.vectors_are_f32(0))
+h.reset_timings()
 t0 = time.perf_counter(); m.rotate(10, 1); out["rotate_s"] = time.perf_counter() - t0
+out["rotate_stages_ms"] = h.timings(); out["varimax_iterations"] = m._varimax_iterations
 t0 = time.perf_counter(); e = m.eofs(10); out["eofs10_s"] = time.perf_counter() - t0
 out["sigma_head"] = [float(x) for x in m._singular_values[:3]]
 print(json.dumps(out))

@@ -610,6 +610,44 @@ def test_rotate_on_resident_vectors_equals_rotate_on_fetched_loadings(name, cplx
         assert _rel(m.norm()[k], got[3][k]) < 1e-10
 
 
+def test_float32_model_keeps_float32_vectors_and_rotates_them_on_the_device():
+    """A real float32 field decomposed on its dual side (the C5 route): `_V` has the input's dtype in the reference
+    (array.py:584), so the back-projection writes float32 (half the store at C5) and rotate() right after solve() builds the
+    float32 loadings float32(V) * float32(sqrt(s)) on the device - the product the reference's host code forms
+    (array.py:818-822).  Same iteration count, R, norms as the host path on the fetched float32 vectors; and EVERY mode has
+    unit norm (advisor, round 3: the 1 / sqrt(lambda) scale of the GEMM epilogue is only used where lambda is clear of the
+    float32 noise of the Gram matrix, the weak modes are normalised by their measured norm)."""
+    from xmca_amd.array import _LazyVectors
+    rng = np.random.default_rng(12)
+    T, N, k = 120, 900, 6
+    X = ((rng.standard_normal((T, k)) * np.linspace(9, 2, k)) @ rng.standard_normal((k, N)) + 0.3 * rng.standard_normal((T, N))).astype(np.float32)
+    X[:, 100:400] *= np.float32(1e-3)                       # a graded field: weak modes far below the leading ones
+    m = MCA(X)
+    m.solve()
+    dev = m._device()
+    assert dev.vectors_are_f32(0) and isinstance(m._V, _LazyVectors) and m._V._pending == set(m._keys)
+    m.rotate(5, 1)
+    assert m._V._pending == set(m._keys)                                          # rotate() fetched nothing
+    got = (m._varimax_iterations, m.rotation_matrix().copy(), m.norm()['left'].copy(), m.variance().copy())
+    m._V.materialize()                                                            # now the host path
+    V = m._V['left']
+    assert V.dtype == np.float32 and V.shape == (N, T)
+    nrm = np.linalg.norm(V.astype(np.float64), axis=0)
+    assert np.max(np.abs(nrm - 1.0)) < 2e-6, (np.argmax(np.abs(nrm - 1.0)), nrm.min(), nrm.max())      # all T modes, null mode included
+    m.rotate(5, 1)
+    assert m._varimax_iterations == got[0]
+    assert _rel(m.rotation_matrix(), got[1]) < 1e-9 and _rel(m.norm()['left'], got[2]) < 1e-9 and _rel(m.variance(), got[3]) < 1e-9
+    # ... and against the oracle (float32 model: 2e-5 on sigma, the reference's own 1e-3 on vectors)
+    om = O.OracleModel(X)
+    om.solve()
+    lead = om.singular_values > 1e-2 * om.singular_values[0]
+    assert np.max(np.abs(m._singular_values[lead] - om.singular_values[lead]) / om.singular_values[lead]) < 2e-5
+    # weak modes of a float32 field: sgesdd itself is only good to eps32 sigma_1 there - an absolute bar
+    assert np.max(np.abs(m._singular_values - om.singular_values)) < 2e-6 * om.singular_values[0]
+    Va, _ = align_modes(V[:, :5].astype(np.float64), om.V[0][:, :5].astype(np.float64))
+    assert np.max(np.abs(Va - om.V[0][:, :5])) < 1e-3
+
+
 def test_unconverged_eigensolver_raises_like_gesdd(monkeypatch):
     """the Jacobi sweeps either reach their stopping rule or the solve raises LinAlgError (numpy's 'SVD did not
     converge'): an unconverged basis is never returned as singular vectors."""

@@ -47,6 +47,7 @@ SIGNATURES = {
     "xmca_correlate": (_c_int, [_vp, _c_int, _vp, _c_i64, _c_i64, _vp]),
     "xmca_project": (_c_int, [_vp, _c_int, _vp, _c_i64, _c_i64, _c_int, _vp, ctypes.POINTER(_c_int)]),
     "xmca_is_complex": (_c_int, [_vp]),
+    "xmca_vectors_are_f32": (_c_int, [_vp, _c_int]),
     "xmca_get_solve_info": (_c_int, [_vp, _vp, _c_int]),
     "xmca_rotate_loadings": (_c_int, [_vp, _vp, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_dbl, _c_int, _c_int, _c_dbl,
                                       _vp, _vp, _vp, _vp, _vp, _ip]),
@@ -74,7 +75,7 @@ def library_path():
     return _build.LIB
 
 
-ABI_VERSION = 6          # bumped whenever a signature of include/xmca_hip.h changes; checked against xmca_abi_version()
+ABI_VERSION = 7          # bumped whenever a signature of include/xmca_hip.h changes; checked against xmca_abi_version()
 
 
 def load_library():
@@ -383,6 +384,10 @@ class Handle:
         self.last_iters = int(iters.value)
         self._check(rc)
         return {"B": None, "R": R, "Phi": Phi, "norm_left": nl, "norm_right": nr, "n_iter": int(iters.value)}
+
+    def vectors_are_f32(self, side=0):
+        """the vectors of the last solve are resident in float32 (real float32 field, dual side): include/xmca_hip.h"""
+        return bool(self._lib.xmca_vectors_are_f32(self._h, int(side)))
 
     def holds_result_of(self, holder):
         ref = getattr(self, "_result_holder", None)

@@ -694,9 +694,11 @@ class MCA:
         dev = self._device()
         V = getattr(self, '_V', None)
         if (isinstance(V, _LazyVectors) and V._pending == set(self._keys) and dev.holds_result_of(self)
-                and n_rot <= self._analysis['rank'] and V._dtype == np.float64):
-            # the vectors of solve() are still resident: the stacked loadings V sqrt(s) are built on the device
-            # (float32 models take the host path: the reference rotates the float32-rounded loadings)
+                and n_rot <= self._analysis['rank'] and (V._dtype == np.float64 or dev.vectors_are_f32(0))):
+            # the vectors of solve() are still resident: the stacked loadings V sqrt(s) are built on the device.  float32
+            # models: the reference rotates float32 loadings (float32 vectors x float32 sqrt(s)) - the device does the same
+            # product when the vectors are resident in float32 (one real field, dual side); any other float32 model
+            # takes the host path below
             out = dev.rotate_solved(n_rot, power=power, tol=tol, max_iter=1000)
         else:
             sqrt_svals = np.sqrt(self._get_svals(n_rot))

@@ -26,6 +26,29 @@ constexpr int ROT_LDP = ROT_PB + 1;
 // state block (doubles): [0]=iter [1]=converged [2]=d [3]=d_old [4]=nan_flag [5]=svd_sweeps(last)
 constexpr int ROT_STATE_N = 8;
 
+// the same for the float32-resident vectors of a real one-field float32 model: L = float(V) * float(sqrt(float(sigma))), a
+// float32 product, exactly the values the reference's host code rotates (array.py:818-822 on float32 `_V` and
+// `_singular_values`); everything after that is float64 like the uploaded-loadings path
+__global__ void rot_build_loadings_f32_kernel(const float* __restrict__ V, int64_t ld, int64_t N, const double* __restrict__ sigma, int p,
+                                              double* __restrict__ Ar, double* __restrict__ h) {
+  for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
+    double acc = 0.0;
+    for (int j = 0; j < p; ++j) {
+      // (float32 square root, correctly rounded: the float64 root of a float32 number rounds to it - 53 > 2 x 24 + 2 bits;
+      // HIP's __fsqrt_rn is the 1-ulp native instruction)
+      const float f = (float)sqrt((double)(float)sigma[j]);
+      const float xf = V[j * ld + n] * f;
+      const double x = (double)xf;
+      Ar[j * N + n] = x;
+      acc += x * x;
+    }
+    const double hn = sqrt(acc);
+    h[n] = hn;
+    const double inv = 1.0 / hn;      // zero rows -> inf*0 = NaN, as in the reference (rotation.py:46-48)
+    for (int j = 0; j < p; ++j) Ar[j * N + n] *= inv;
+  }
+}
+
 // L[j][n] = V_side[j][n - off] * sqrt(sigma_j) for the concatenated sides; A = L / h, h = row norms over j
 template <bool CPLX>
 __global__ void rot_build_loadings_kernel(const double* __restrict__ Vlr, const double* __restrict__ Vli, int64_t ldl, int64_t Nl,

@@ -110,6 +110,8 @@ struct SolveResult {
   int n_vec = 0;                       // back-projected modes
   std::vector<double> sigma;           // singular values of A^H B / (T-1), descending
   CPlanes Vt[2];                       // n_vec x N_k planes (row m = mode m)
+  DevBuf<float> Vt32[2];               // ... or, vt_f32[side], ONE float32 plane: a real float32 field reduced on the dual side keeps
+  bool vt_f32[2] = {false, false};     // its vectors in the model's dtype, as the reference does (`_V` follows the input, array.py:584)
   int64_t ldv[2] = {0, 0};
   bool cplx = false;
   bool weak_refined = false;          // the route refined its weak modes itself (Solver::refine_weak_block)
@@ -127,6 +129,7 @@ class Solver {
   GemmWorkspace& gws;
   EvdWorkspace& ews;
   StageTimer& tm;
+  bool f32_vectors = false;    // xmca_solve on float32 fields: vectors of the one-field dual route stay float32 (SolveResult::Vt32)
   Solver(hipStream_t s, GemmWorkspace& g, EvdWorkspace& e, StageTimer& t) : st(s), gws(g), ews(e), tm(t) {}
 
   // per-field reduction: eigen-decomposition of the T x T Gram matrix when N > T
@@ -178,16 +181,37 @@ class Solver {
   // eigenvector basis of the Gram matrix, ||u_k^H X~|| = sqrt(lambda_k) - so that 1 / norm rides in the GEMM epilogue and the
   // conjugation in the operand flags: no second pass over the m x N result (C5: 6.4 ms and 10 GB of traffic).  Rows
   // beyond n_known (null modes: their norm is rounding noise) are normalised by what they are.
+  // `Vt32` (float32 fields, real): the result is written in float32 by the GEMM's epilogue - the reference's `_V` has the
+  // input's dtype (array.py:584), and at C5 the float64 result is a 10 GB store against 5 GB.
   void back_project(const FieldData<TI>& f, bool cplx, const double* Yr, const double* Yi, int m, CPlanes& Vt,
-                    const double* row_norm = nullptr, int n_known = 0) {
+                    const double* row_norm = nullptr, int n_known = 0, DevBuf<float>* Vt32 = nullptr) {
     const int T = (int)f.T;
     Narrow<TI> y;
     y.from(st, Yr, Yi, (int64_t)m * T);
-    Vt.ensure((size_t)m * f.N, cplx);
     DevBuf<double> inv_dev;
     std::vector<double> inv_host;
-    static const bool epilogue_on = [] { const char* e = std::getenv("XMCA_BACKPROJECT_EPILOGUE"); return !(e && e[0] == '0'); }();
-    if (!row_norm || !epilogue_on) n_known = 0;
+    if (!row_norm) n_known = 0;
+    if constexpr (std::is_same<TI, float>::value) {
+      if (Vt32 && !cplx) {
+        float* V = Vt32->ensure((size_t)m * f.N);
+        GemmOpts o;
+        o.a_kfast = true; o.b_nfast = true;
+        if (n_known > 0) {
+          inv_host.assign((size_t)m, 1.0);
+          for (int k = 0; k < n_known; ++k) inv_host[(size_t)k] = 1.0 / row_norm[k];
+          XMCA_HIP(hipMemcpyAsync(inv_dev.ensure((size_t)m), inv_host.data(), sizeof(double) * m, hipMemcpyHostToDevice, st));
+          o.row_scale = inv_dev.get();
+        }
+        gemm<float, float>(st, gws, y.r, T, f.r(), f.N, V, f.N, m, (int)f.N, T, o);
+        if (n_known < m)
+          hipLaunchKernelGGL((normalize_rows_kernel<float>), dim3(m - n_known), dim3(256), 0, st, V + (int64_t)n_known * f.N, (float*)nullptr,
+                             f.N, (int)f.N, 0, (double*)nullptr);
+        XMCA_HIP(hipGetLastError());
+        XMCA_HIP(hipStreamSynchronize(st));
+        return;
+      }
+    }
+    Vt.ensure((size_t)m * f.N, cplx);
     if (n_known > 0) {
       inv_host.assign((size_t)m, 1.0);
       for (int k = 0; k < n_known; ++k) inv_host[(size_t)k] = 1.0 / row_norm[k];
@@ -212,6 +236,7 @@ class Solver {
   void solve(const FieldData<TI>* fields, int n_fields, bool cplx, int n_vec_req, SolveResult& out) {
     out.weak_refined = false;            // (the caller may hand in the result object of an earlier solve)
     out.consistent = 0;
+    out.vt_f32[0] = out.vt_f32[1] = false;
     for (EvdInfo& e : out.evd_info) e = EvdInfo();
     solve_core(fields, n_fields, cplx, n_vec_req, out);
     if (n_fields == 2) refine_by_deflation(fields, cplx, out);
@@ -369,11 +394,17 @@ class Solver {
         out.ldv[0] = A.N;
         tm.begin("backproject");
         if (m > 0) {
-          // ||u_k^H X~|| = sqrt(lambda_k) for every mode clear of the rounding noise of the Gram matrix
+          // ||u_k^H X~|| = sqrt(lambda_k) for every mode clear of the rounding noise of the Gram matrix: lambda_k carries an
+          // absolute error of ~1e-7 lambda_0 for float32 fields (f32 products) and ~1e-14 lambda_0 for float64 ones (the
+          // tridiagonal route), so 1 / sqrt(lambda_k) is a unit-norm scale to 1e-3 / 1e-8 above these cuts; the modes below
+          // them are normalised by their measured norm (advisor, round 3: a dtype-blind 1e-9 left weak float32 modes off unit norm)
+          const double cut = (std::is_same<TI, float>::value ? 1e-4 : 1e-6) * Ra.lam[0];
           std::vector<double> nrm((size_t)m, 0.0);
           int known = 0;
-          while (known < m && Ra.lam[(size_t)known] > 1e-9 * Ra.lam[0]) { nrm[(size_t)known] = std::sqrt(Ra.lam[(size_t)known]); ++known; }
-          back_project(A, cplx, Ra.Z.r(), Ra.Z.i(cplx), m, out.Vt[0], nrm.data(), known);
+          while (known < m && Ra.lam[(size_t)known] > cut) { nrm[(size_t)known] = std::sqrt(Ra.lam[(size_t)known]); ++known; }
+          const bool v32 = f32_vectors && std::is_same<TI, float>::value && !cplx;
+          out.vt_f32[0] = v32;
+          back_project(A, cplx, Ra.Z.r(), Ra.Z.i(cplx), m, out.Vt[0], nrm.data(), known, v32 ? &out.Vt32[0] : nullptr);
         }
         tm.end();
       } else {
@@ -967,6 +998,7 @@ class Solver {
   }
 
   void solve_analytic(const FieldData<TI>* fields, int n_fields, int n_vec_req, SolveResult& out) {
+    out.vt_f32[0] = out.vt_f32[1] = false;     // (complex vectors: float64 planes)
     const FieldData<TI>& A = fields[0];
     const int T = (int)A.T;
     const double dof = (double)(T - 1);

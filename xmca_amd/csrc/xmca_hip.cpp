@@ -179,6 +179,7 @@ void solve_impl(xmca_handle* h, int n_fields, int64_t n_vec) {
   const bool cplx = f[0].has_im;
   if (n_fields == 2) XMCA_CHECK(f[1].has_im == cplx, XMCA_ERR_INVALID, "solve: both fields must be real or both complex");
   Solver<TI> s(h->st, h->gws, h->ews, h->tm);
+  s.f32_vectors = true;          // (only the one-field dual route of a real float32 field uses it)
   s.solve(f, n_fields, cplx, (int)n_vec, h->res);
 }
 
@@ -188,6 +189,19 @@ void get_vectors_impl(xmca_handle* h, int side, void* out, int64_t m) {
   const int64_t N = r.ldv[side];
   const bool cplx = r.cplx;
   const size_t n_out = (size_t)m * N * (cplx ? 2 : 1);
+  if (r.vt_f32[side]) {              // float32-resident vectors (real, dense m x N): straight out, or widened
+    if constexpr (std::is_same<TO, float>::value) {
+      XMCA_HIP(hipMemcpyAsync(out, r.Vt32[side].get(), n_out * sizeof(float), hipMemcpyDeviceToHost, h->st));
+    } else {
+      DevBuf<TO> wide;
+      hipLaunchKernelGGL((convert_kernel<float, TO>), ew_grid((int64_t)n_out), dim3(EW_BLOCK), 0, h->st, r.Vt32[side].get(), wide.ensure(n_out),
+                         (int64_t)n_out);
+      XMCA_HIP(hipGetLastError());
+      XMCA_HIP(hipMemcpyAsync(out, wide.get(), n_out * sizeof(TO), hipMemcpyDeviceToHost, h->st));
+    }
+    XMCA_HIP(hipStreamSynchronize(h->st));
+    return;
+  }
   DevBuf<TO> tmp;
   tmp.ensure(n_out);
   hipLaunchKernelGGL((pack_rows_kernel<TO>), ew_grid((int64_t)m * N), dim3(EW_BLOCK), 0, h->st, r.Vt[side].r(), r.Vt[side].i(cplx), N,
@@ -810,6 +824,10 @@ int xmca_get_singular_values(xmca_handle* h, double* out, int64_t n) {
 
 int xmca_is_complex(xmca_handle* h) { return (h && h->solved && h->res.cplx) ? 1 : 0; }
 
+int xmca_vectors_are_f32(xmca_handle* h, int side) {
+  return (h && h->solved && (side == 0 || side == 1) && h->res.vt_f32[side]) ? 1 : 0;
+}
+
 int xmca_get_solve_info(xmca_handle* h, int* info, int n) {
   if (!h || !info) return XMCA_ERR_INVALID;
   for (int i = 0; i < n && i < 9; ++i) {
@@ -985,7 +1003,14 @@ int xmca_rotate_solved(xmca_handle* h, int p, int power, double tol, int max_ite
   const CPlanes& Vr = r.Vt[Nr > 0 ? 1 : 0];
   RotateResult rr;
   // loadings of both fields stacked, V sqrt(sigma) (array.py:818-822), built where the vectors are
-  if (cplx) {
+  if (r.vt_f32[0]) {
+    // float32 model (one real field): the reference multiplies the float32 vectors by the float32 square roots of the float32
+    // singular values - a float32 product - and rotates that; the same roundings here, then float64 like the host path
+    XMCA_CHECK(!cplx && Nr == 0, XMCA_ERR_STATE, "rotate: float32-resident vectors are real and one-sided");
+    hipLaunchKernelGGL(rot_build_loadings_f32_kernel, ew_grid(Nl), dim3(EW_BLOCK), 0, h->st, r.Vt32[0].get(), Nl, Nl, sigma_dev.get(), p, d.A.r(),
+                       d.h.get());
+    rot.run<false>(d, power, tol, max_iter, rr, nullptr, false);
+  } else if (cplx) {
     hipLaunchKernelGGL((rot_build_loadings_kernel<true>), ew_grid(Nl + Nr), dim3(EW_BLOCK), 0, h->st, Vl.r(), Vl.i(true), Nl, Nl,
                        Vr.r(), Vr.i(true), Nr > 0 ? Nr : Nl, Nr, sigma_dev.get(), p, d.A.r(), d.A.i(true), d.h.get());
     rot.run<true>(d, power, tol, max_iter, rr, nullptr, false);
