@@ -138,6 +138,10 @@ int xmca_is_complex(xmca_handle* h);
  * `VLT.conjugate().T`), and xmca_rotate_solved then multiplies float32 vectors by float32 sqrt(singular values) like the
  * reference's host code (array.py:818-822).  Every other result is float64 planes. */
 int xmca_vectors_are_f32(xmca_handle* h, int side);
+/* Persistent launches of this process (the register-resident tridiagonal reduction, the one-launch Varimax loop) that ran out
+ * of their bounded waits because a workgroup never became resident, and were repeated on the launch-per-step path.  All
+ * persistent kernels of a device pass one gate (csrc/common.h PersistGate), so this stays 0 unless ANOTHER process holds CUs. */
+long long xmca_persistent_giveups(void);
 /* Diagnostics of the last solve: for each of the up to three eigen-decompositions (left Gram, right Gram, kernel):
  * info[3*i + 0] = outer sweeps, info[3*i + 1] = tile size, info[3*i + 2] = pair slots (i = 0..2), then
  * info[9 + i]: bit 0 = the eigensolver inserted a Cholesky LR step (graded spectrum), bit 1 = the problem was solved by

@@ -338,6 +338,33 @@ def test_bench_py_reports_the_tridiagonal_reduction_as_its_dominant_kernel():
     assert g["bound"] == "mfma" and 0 < g["frac"] < 1 and g["kernel"].startswith("gemm_kernel")
 
 
+def test_persistent_kernels_of_four_lanes_pass_one_gate():
+    """Rotated rule_n with four surrogates in flight, at a size where every surrogate runs BOTH persistent kernels of the
+    library - the register-resident tridiagonal reduction (n = 800 with vectors: every CU) and the one-launch Varimax loop (a
+    grid of its own per lane).  Round 3 serialised only the reductions; a Varimax grid of another lane could interleave with
+    one, and the two partly resident grids then waited for each other until the bounded spins gave up (~0.2 s) and the work
+    was repeated launch by launch.  All persistent launches of a device now pass one gate (csrc/common.h PersistGate): no
+    give-up, and the call takes what the kernels take."""
+    import subprocess
+    code = ("import sys, time, json, numpy as np; sys.path.insert(0, %r); from xmca_amd import _hip; h = _hip.Handle(0);"
+            "args = (800, 2000, 0, 1, False, True, 6, 1, 1e-8);"
+            "h.rule_n(*args, 0, 4, 5, np.float64, 6);"                                     # warm-up: lanes, workspaces
+            "g0 = _hip.load_library().xmca_persistent_giveups(); h.reset_timings(); t0 = time.perf_counter();"
+            "sp, kept = h.rule_n(*args, 0, 16, 5, np.float64, 6); dt = time.perf_counter() - t0;"
+            "tm = h.timings();"
+            "print(json.dumps({'seconds': dt, 'giveups': _hip.load_library().xmca_persistent_giveups() - g0, 'kept': int(kept.sum()),"
+            " 'resident': tm.get('trd_resident_calls', 0), 'reductions': tm.get('trd_reduce_calls', 0)}))" % REPO)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, XMCA_RULE_N_LANES="4", XMCA_TRACE="giveup"), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["giveups"] == 0, r.stderr[-1000:]
+    assert out["kept"] >= 12                                           # (a white-noise surrogate may not converge in 1000 iterations: dropped)
+    assert out["reductions"] == 16 and out["resident"] == 16          # every surrogate: one reduction, by the persistent kernel
+    assert out["seconds"] < 16 * 0.05                                  # ~15 ms of kernels per surrogate; one give-up alone costs 0.2 s
+
+
 def test_rule_n_spectra_do_not_depend_on_the_number_of_lanes():
     """xmca_rule_n keeps several surrogates in flight (one stream + workspaces + host thread per lane, xmca_hip.cpp
     rule_n_impl); the generator is keyed by (seed, run, side), so 1, 2, 3 and 5 lanes must give the same bits - unrotated,

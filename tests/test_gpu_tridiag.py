@@ -48,21 +48,17 @@ def test_eigenvalues_only_match_lapack(hip, monkeypatch, n, cplx, resident):
 
 
 @pytest.mark.parametrize("n,cplx", [(130, False), (193, True), (1000, False), (900, True)])
-def test_back_transformation_block_sizes_agree(hip, monkeypatch, n, cplx):
-    """Blocks of 128 reflectors (default: the 128 x 128 WY system solved as two halves of 64 with one product in between; the last
-    block is shorter, here also shorter than 64 or just above it) against blocks of 64: the same eigenvectors to rounding."""
+def test_back_transformation_with_short_last_blocks(hip, monkeypatch, n, cplx):
+    """Blocks of 128 reflectors (the 128 x 128 WY system solved as two halves of 64 with one product in between); the last
+    block is shorter, here also shorter than 64 or just above it: a full orthonormal decomposition all the same."""
     monkeypatch.setenv("XMCA_TRIDIAG_VEC_MIN_N", "2")
     G = _gram(n, cplx)
     lam, U = hip.eigh(G)
     assert hip.last_eigh_info["tridiag"] == 1
-    monkeypatch.setenv("XMCA_TRD_WY_BLOCK", "64")
-    lam64, U64 = hip.eigh(G)
-    assert hip.last_eigh_info["tridiag"] == 1
-    assert np.array_equal(lam, lam64)
-    assert np.max(np.abs(U.conj().T @ U - np.eye(n))) < 1e-12 and np.max(np.abs(U64.conj().T @ U64 - np.eye(n))) < 1e-12
-    # the same vectors up to the rounding of two different summation orders (well separated part of the spectrum)
-    ov = np.abs(np.sum(U[:, :20].conj() * U64[:, :20], axis=0))
-    assert np.max(np.abs(ov - 1.0)) < 1e-10
+    ref = np.linalg.eigvalsh(G)[::-1]
+    assert np.max(np.abs(lam - ref)) < 1e-13 * ref[0]
+    assert np.max(np.abs(U.conj().T @ U - np.eye(n))) < 1e-12
+    assert np.max(np.linalg.norm(G @ U - U * lam, axis=0)) < 1e-12 * ref[0]
 
 
 @pytest.mark.parametrize("resident", ["tagged", "flags", "0"])

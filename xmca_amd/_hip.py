@@ -48,6 +48,7 @@ SIGNATURES = {
     "xmca_project": (_c_int, [_vp, _c_int, _vp, _c_i64, _c_i64, _c_int, _vp, ctypes.POINTER(_c_int)]),
     "xmca_is_complex": (_c_int, [_vp]),
     "xmca_vectors_are_f32": (_c_int, [_vp, _c_int]),
+    "xmca_persistent_giveups": (ctypes.c_longlong, []),
     "xmca_get_solve_info": (_c_int, [_vp, _vp, _c_int]),
     "xmca_rotate_loadings": (_c_int, [_vp, _vp, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_dbl, _c_int, _c_int, _c_dbl,
                                       _vp, _vp, _vp, _vp, _vp, _ip]),

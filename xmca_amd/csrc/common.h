@@ -7,6 +7,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
+#include <condition_variable>
 #include <map>
 #include <mutex>
 #include <stdexcept>
@@ -192,6 +194,66 @@ struct DevBuf {
   }
   T* get() const { return p; }
 };
+
+// One gate per device for EVERY persistent kernel of the library - kernels whose workgroups wait for each other inside the
+// launch (trd_resident_kernel: every CU, exclusively; varimax_persistent_kernel: one CU per workgroup of its grid).  Two such
+// grids in flight on one device - the surrogate lanes of rule_n / bootstrapping run on their own streams and threads - can
+// each hold a part of the CUs and wait for the rest: bounded spins end it, but only after ~0.2 s and a rerun.  A launch
+// claims the CUs its grid needs and waits on the HOST for its turn; the claim is given back when the stream has finished the
+// kernel.  Ordinary kernels are not counted: they always finish, so a persistent grid only waits for them.
+struct PersistGate {
+  std::mutex mu;
+  std::condition_variable cv;
+  int n_cus = 256;
+  int used = 0;
+  void acquire(int cus) {
+    std::unique_lock<std::mutex> lk(mu);
+    if (cus > n_cus) cus = n_cus;
+    cv.wait(lk, [&] { return used + cus <= n_cus; });
+    used += cus;
+  }
+  void release(int cus) {
+    { std::lock_guard<std::mutex> lk(mu); used -= cus > n_cus ? n_cus : cus; }
+    cv.notify_all();
+  }
+  struct Claim {                       // RAII: acquire on construction (cus > 0), release on destruction / release()
+    PersistGate* g; int cus;
+    Claim(PersistGate& gate, int c) : g(&gate), cus(c) { if (cus > 0) g->acquire(cus); }
+    void release() { if (cus > 0) { g->release(cus); cus = 0; } }
+    ~Claim() { release(); }
+    Claim(const Claim&) = delete;
+    Claim& operator=(const Claim&) = delete;
+  };
+};
+// persistent launches of this process that ran out of their bounded spins (a workgroup never became resident) and were
+// repeated on the launch-per-step path: 0 unless another process holds CUs (xmca_persistent_giveups)
+inline std::atomic<long long>& persist_giveups() {
+  static std::atomic<long long> n{0};
+  return n;
+}
+inline PersistGate& persist_gate() {   // of the calling thread's current device
+  static std::mutex mu;
+  static std::map<int, PersistGate*>* gates = new std::map<int, PersistGate*>;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = gates->find(dev);
+  if (it != gates->end()) return *it->second;
+  PersistGate* g = new PersistGate;
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) g->n_cus = n;
+  (*gates)[dev] = g;
+  return *g;
+}
+
+// XMCA_TRACE=jacobi,solve,rot (any subset, or "all"): progress lines of the eigensolver sweeps / the solver's route and
+// consistency decisions / the rotation loop on stderr.  One switch instead of three.
+static inline bool xmca_trace(const char* what) {
+  const char* e = std::getenv("XMCA_TRACE");
+  if (!e || !e[0]) return false;
+  const std::string s(e);
+  return s.find("all") != std::string::npos || s.find(what) != std::string::npos;
+}
 
 static inline int ceil_div(int64_t a, int64_t b) { return static_cast<int>((a + b - 1) / b); }
 

@@ -183,7 +183,6 @@ inline void hermitian_evd(hipStream_t st, EvdWorkspace& ws, const double* Ar, co
   // 1e-8 left behind bounds that by ~n 1e-16 lam_max for a spectrum without exact clusters, and the sweep that would
   // push the vectors' first-order error down is not needed (C4 surrogates: 12 -> 11 sweeps)
   if (!Zr) prm.tol = 1e-8;
-  if (const char* e = std::getenv("XMCA_JACOBI_TOL")) { if (std::atof(e) > 0.0) prm.tol = std::atof(e); }   // (experiments: scripts/eigh_tol_probe.py)
   hermitian_evd_f64(st, ws, Ar, Ai, n, lda, lam_host, lam_dev, Zr, Zi, ldz, prm, info, force_tile);
 }
 

@@ -650,7 +650,7 @@ class Solver {
         worst_c = std::max(worst_c, dev);
       }
       out.consistent = ok;
-      static const bool trace = std::getenv("XMCA_SOLVE_TRACE") != nullptr;
+      static const bool trace = xmca_trace("solve");
       if (trace)
         std::fprintf(stderr, "[xmca solve] one-sided (time space): left-vector coherence %.3e over %d modes; sigma consistent (%.1e) for the "
                              "leading %d of %d modes, sigma there %.2e sigma_1\n", worst, n_check, worst_c, ok, m,
@@ -1097,7 +1097,7 @@ class Solver {
           while (n_check < nv && out.sigma[n_check] > 1e-9 * out.sigma[0]) ++n_check;
           const double worst = coherence(El, Gya, nv, m, n_check, true);
           tm.end();
-          static const bool trace = std::getenv("XMCA_SOLVE_TRACE") != nullptr;
+          static const bool trace = xmca_trace("solve");
           if (trace) std::fprintf(stderr, "[xmca solve] Cholesky factor: left-vector coherence %.3e over %d modes\n", worst, n_check);
           if (!(worst < 1e-6)) return false;
         }
@@ -1308,7 +1308,7 @@ class Rotator {
   static bool wide_grid(int p, bool cplx) { return (size_t)p * p * (cplx ? 2 : 1) >= 512; }
   static int pick_nwg(int64_t N, bool wide = false) {
     const int64_t nb = (N + ROT_PB - 1) / ROT_PB;
-    static const int cap_env = [] { const char* e = std::getenv("XMCA_ROT_WGS"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 0; }();
+    constexpr int cap_env = 0;
     const int cap = cap_env > 0 ? cap_env : (wide ? 256 : 128);
     // equal shares: with 157 tiles and a cap of 128 workgroups, 79 workgroups of 2 tiles beat 128 of 1-2
     const int64_t per = (nb + cap - 1) / cap;
@@ -1382,40 +1382,15 @@ class Rotator {
     if (resident) persist_smem += rot_resident_smem(p, CPLX, tiles_per_wg);
     // the epoch exchange spins on every workgroup of the grid: all of them must be co-resident, one per CU (a
     // partitioned / CU-masked device has fewer CUs than the 128-workgroup cap -> per-iteration launches instead)
-    static const int n_cus = [] {
-      int dev = 0, n = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
-      return n;
-    }();
+    PersistGate& gate = persist_gate();
+    const int n_cus = gate.n_cus;
     // ... and so must the persistent grids of the OTHER surrogate lanes of this process (rule_n / bootstrap keep several
-    // replicates in flight): a process-wide budget of workgroups in flight; a launch that would exceed the CU count takes
-    // the per-iteration launches instead of relying on the bounded spins
-    static std::atomic<int> persist_inflight{0};
-    bool persist_ok = fused && persist_on && persist_smem <= 160 * 1024 && d.nwg <= 256 && d.nwg <= n_cus && max_iter > 0;
+    // replicates in flight), Varimax loops and tridiagonal reductions alike: the launch claims its CUs at the device's gate
+    // (common.h PersistGate) and waits there for its turn - a reduction holds every CU for its ~20 ms, Varimax grids of
+    // several lanes run side by side while they fit
+    const bool persist_ok = fused && persist_on && persist_smem <= 160 * 1024 && d.nwg <= 256 && d.nwg <= n_cus && max_iter > 0;
     if (persist_ok) {
-      if (persist_inflight.fetch_add(d.nwg) + d.nwg > n_cus) {
-        persist_inflight.fetch_sub(d.nwg);
-        persist_ok = false;
-        // a wide grid next to another lane's: try again with the narrow one (the buffers are large enough for either)
-        const int narrow = pick_nwg(d.N, false);
-        const int tiles_narrow = (int)(((d.N + ROT_PB - 1) / ROT_PB + narrow - 1) / narrow);
-        if (narrow < d.nwg && persist_inflight.fetch_add(narrow) + narrow <= n_cus) {
-          d.nwg = narrow;
-          persist_ok = true;
-          persist_smem = rot_persistent_smem(p, CPLX);
-          resident = persist_smem + rot_resident_smem(p, CPLX, tiles_narrow) <= 160 * 1024;
-          tiles_per_wg = tiles_narrow;
-          if (resident) persist_smem += rot_resident_smem(p, CPLX, tiles_per_wg);
-        } else if (narrow < d.nwg) {
-          persist_inflight.fetch_sub(narrow);
-        }
-      }
-    }
-    struct InflightGuard {
-      std::atomic<int>& c; int n; bool on;
-      ~InflightGuard() { if (on) c.fetch_sub(n); }
-    } inflight_guard{persist_inflight, d.nwg, persist_ok};
-    if (persist_ok) {
+      PersistGate::Claim claim(gate, d.nwg);           // given back at the end of this block: the stream has been synchronised by then
       // XMCA_VARIMAX_TEST_GIVEUP=k (tests): the persistent launch stops after k iterations, as if a workgroup had gone
       // missing there, and the per-iteration launches take over - the hand-over must not change R or the stop iteration
       const char* tg = std::getenv("XMCA_VARIMAX_TEST_GIVEUP");
@@ -1426,7 +1401,7 @@ class Rotator {
       XMCA_HIP(hipMemsetAsync(d.pflags.get(), 0, sizeof(unsigned int) * 2 * d.nwg, st));
       // two-stage sum of the partials when every workgroup would otherwise read more than ~32k doubles (XMCA_ROT_TWO_STAGE=0 / 1 forces)
       const bool rot_two_stage = [&] { const char* e = std::getenv("XMCA_ROT_TWO_STAGE"); return e ? e[0] != '0' : (size_t)d.nwg * p * p * (CPLX ? 2 : 1) > 32768; }();
-      const int rot_poll_delay = [] { const char* e = std::getenv("XMCA_ROT_POLL_DELAY"); return e ? std::atoi(e) : 0; }();   // (no measurable effect here: 0)
+      constexpr int rot_poll_delay = 0;     // (a delayed first poll, the lever of the tridiagonal reduction, has no measurable effect here)
       XMCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(varimax_persistent_kernel<CPLX>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_smem));
       hipLaunchKernelGGL((varimax_persistent_kernel<CPLX>), dim3(d.nwg), dim3(256), persist_smem, st, d.A.r(), d.A.i(CPLX), d.h.get(),
@@ -1441,6 +1416,8 @@ class Rotator {
         // a workgroup never arrived (grid not resident: another process holds CUs).  Workgroup 0 has written the R, c
         // and iteration state of the last completed iteration: clear the flag and let the per-iteration launches below
         // finish the loop from there.
+        ++persist_giveups();
+        if (xmca_trace("giveup")) std::fprintf(stderr, "xmca: varimax_persistent_kernel (%d workgroups) gave up after %d iterations\n", d.nwg, (int)state[0]);
         state[4] = 0.0;
         XMCA_HIP(hipMemcpyAsync(d.state.get(), state, sizeof(state), hipMemcpyHostToDevice, st));
         XMCA_HIP(hipStreamSynchronize(st));
@@ -1466,7 +1443,7 @@ class Rotator {
       launched += batch;
       XMCA_HIP(hipMemcpyAsync(state, d.state.get(), sizeof(state), hipMemcpyDeviceToHost, st));
       XMCA_HIP(hipStreamSynchronize(st));
-      static const bool trace = std::getenv("XMCA_ROT_TRACE") != nullptr;
+      static const bool trace = xmca_trace("rot");
       if (trace)
         std::fprintf(stderr, "[xmca varimax] p=%d N=%lld cplx=%d launched=%d iter=%g conv=%g d=%.12g polar_its=%g nan=%g\n", p,
                      (long long)d.N, (int)CPLX, launched, state[0], state[1], state[2], state[5], state[4]);

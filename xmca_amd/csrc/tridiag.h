@@ -557,7 +557,7 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
             }
           }
           if (__all(all)) break;
-          if (++spins > (1u << 17)) { give_up_sh = 1; break; }       // (~0.2 s) a workgroup is missing: report, never hang
+          if (++spins > (1u << 20)) { give_up_sh = 1; break; }       // (~1.5 s) a workgroup is missing: report, never hang.  All persistent launches of THIS process pass one gate (common.h), so only a foreign process can cause it; 0.2 s (round 3) was less than the first launch on a cold device can take
           __builtin_amdgcn_s_sleep(1);
         }
       }
@@ -929,7 +929,7 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
             ok &= __hip_atomic_load(flags + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned int)(j + 1);
           if (__all(ok)) break;
           __builtin_amdgcn_s_sleep(1);
-          if (++spins > (1u << 17)) { if (lane == 0) give_up_sh = 1; break; }     // (~0.2 s) a workgroup is missing: report, never hang
+          if (++spins > (1u << 20)) { if (lane == 0) give_up_sh = 1; break; }     // (~1.5 s) a workgroup is missing: report, never hang
         }
       }
     }
@@ -1146,10 +1146,6 @@ struct TrdLayout {
   static size_t doubles(size_t nv) { return nv * 12 + (size_t)TRD_MAX_WGS * 8; }
 };
 
-inline std::mutex& trd_resident_mutex() {
-  static std::mutex* m = new std::mutex;
-  return *m;
-}
 
 // resident form: chunks of 128 columns per row (NC) and rows per wave (RR) by problem kind; 0 = does not fit
 inline int trd_resident_nc(int n, bool cplx) {
@@ -1195,11 +1191,8 @@ inline TrdParams trd_reduce(hipStream_t st, TrdWorkspace& ws, const double* Ar, 
 
   // ---- persistent form: the trailing matrix in registers, one exchange per column ----
   if (nc > 0) {
-    static const int n_cus = [] {
-      int dev = 0, v = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
-      return v > 0 ? v : 256;
-    }();
+    PersistGate& gate = persist_gate();       // (per device: CU count and the claims of every persistent kernel)
+    const int n_cus = gate.n_cus;
     const int rr = cplx ? (nc == 8 ? 1 : 2) : nc / 8;     // row slots per wave: all of the matrix (real), the last 2048 rows (complex)
     const int wgs = std::max(1, std::min(std::min(n_cus, TRD_MAX_WGS), ceil_div(n, (TRD_RES_THREADS / 64) * rr)));
     const int first_res = std::max(0, n - wgs * (TRD_RES_THREADS / 64) * rr);
@@ -1216,8 +1209,8 @@ inline TrdParams trd_reduce(hipStream_t st, TrdWorkspace& ws, const double* Ar, 
     for (int a = 0; a < 2; ++a) for (int c = 0; c < 2; ++c) { S.gpart[a][c] = q; q += TRD_MAX_WGS; }
     for (int a = 0; a < 2; ++a) for (int c = 0; c < 2; ++c) { S.rowbuf[a][c] = q; q += lv; }
     S.flags = ws.flags.get();
-    { const char* e = std::getenv("XMCA_TRD_POLL_DELAY"); S.poll_delay = e ? std::atoi(e) : 16; }
-    { const char* e = std::getenv("XMCA_TRD_TAG_DELAY"); S.tag_delay = e ? std::max(0, std::min(256, std::atoi(e))) : 24; }   // (real: 0 -> 23.4 ms at n = 2920, 4.77 at 1000; 24 -> 22.4, 3.72)
+    S.poll_delay = 16;      // (flags form; swept 8...48 in round 3: flat)
+    S.tag_delay = 24;       // swept 0...48 in rounds 3 and 4: flat optimum 20-28, real and complex   // (real: 0 -> 23.4 ms at n = 2920, 4.77 at 1000; 24 -> 22.4, 3.72)
     // column 0 reads its row like every other column: from rowbuf (parity 0)
     // (the tagged form reads row 0 from the working copy: the exchange buffers must start as zeros)
     // exchange by tagged values or by epoch flags.  Measured with the request delay tuned (XMCA_TRD_TAG_DELAY), tagged / flags:
@@ -1248,9 +1241,9 @@ inline TrdParams trd_reduce(hipStream_t st, TrdWorkspace& ws, const double* Ar, 
     }
     int gave_up = 0;
     {
-      // one persistent grid at a time per process: two of them (two surrogate lanes) could each hold a part of the CUs
-      // and wait for the rest forever (bounded here, but slow)
-      std::lock_guard<std::mutex> lock(trd_resident_mutex());
+      // every CU of the device, exclusively among the persistent kernels (common.h PersistGate): held until the stream
+      // has finished the reduction
+      PersistGate::Claim claim(gate, n_cus);
       ws.ev_begin(st);
       hipLaunchKernelGGL(fn, dim3(wgs), dim3(TRD_RES_THREADS), lds, st, P, S, first_res);
       ws.ev_end(st);
@@ -1279,6 +1272,8 @@ inline TrdParams trd_reduce(hipStream_t st, TrdWorkspace& ws, const double* Ar, 
     ws.ev_pending = false;
     // a workgroup never became resident (another process holds CUs?): start again with one launch per column
     ws.resident_used = 2;
+    ++persist_giveups();
+    if (xmca_trace("giveup")) std::fprintf(stderr, "xmca: trd_resident_kernel (n = %d) gave up - repeated with one launch per column\n", n);
     hipLaunchKernelGGL(trd_copy_kernel, dim3(n), dim3(256), 0, st, Ar, Ai, n, lda, P.Ar, P.Ai, ld, ws.scal.get());
     XMCA_HIP(hipMemsetAsync(ws.vec.get(), 0, sizeof(double) * TrdLayout::doubles(nv), st));
     if (keep_reflectors) {

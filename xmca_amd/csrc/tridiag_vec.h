@@ -331,7 +331,7 @@ inline bool trd_eigenvectors(hipStream_t st, TrdWorkspace& ws, TrdVecWorkspace& 
   const int64_t ldv = P.ld;                                   // reflectors
   // reflectors per block of the back-transformation: 128 (two skinny GEMMs per block at twice the depth, half the passes over
   // Z; the 128 x 128 system T^{-1} X = W is solved in two halves of 64 with one small product in between) or 64
-  const int NBK = [] { const char* e = std::getenv("XMCA_TRD_WY_BLOCK"); return (e && std::atoi(e) == 64) ? 64 : 128; }();
+  constexpr int NBK = 128;       // (blocks of 64 - round 3's first form - took 8.1 instead of 6.5 ms at n = 2920)
   const int64_t ld = ((int64_t)n + NBK + 15) & ~(int64_t)15;   // Z with NBK extra columns (the block's reflectors, see trd_vcopy_kernel)
   const size_t plane = (size_t)n * ld;
   double* Yr = vw.Y[0].ensure(plane);

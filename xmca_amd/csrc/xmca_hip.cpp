@@ -824,6 +824,8 @@ int xmca_get_singular_values(xmca_handle* h, double* out, int64_t n) {
 
 int xmca_is_complex(xmca_handle* h) { return (h && h->solved && h->res.cplx) ? 1 : 0; }
 
+long long xmca_persistent_giveups(void) { return (long long)::xmca::persist_giveups().load(); }
+
 int xmca_vectors_are_f32(xmca_handle* h, int side) {
   return (h && h->solved && (side == 0 || side == 1) && h->res.vt_f32[side]) ? 1 : 0;
 }
