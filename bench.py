@@ -108,15 +108,17 @@ def csrc_hash():
     return hh.hexdigest()[:16]
 
 
-PMC_FILE = os.path.join("profiles", "r03_pmc_c2.json")
+PMC_FILE = os.path.join("profiles", "r04_pmc_c2.json")                 # counter passes of the C2 step (scripts/r04_profiles.sh)
+PMC_GRAM_C2 = os.path.join("profiles", "r04_pmc_gram_c2.json")         # ... of the Gram product alone (scripts/gram_only.py c2)
+PMC_GRAM_C5 = os.path.join("profiles", "r04_pmc_gram_c5.json")         # ... and at C5
 
 
-def pmc_traffic(kernel, same_workload):
-    """HBM-side bytes per launch of `kernel` from the committed PMC passes (profiles/r03_pmc_c2.json: separate rocprofv3 --pmc
-    runs of `bench.py --steps 1` at the default workload, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
-    The file carries the hash of xmca_amd/csrc it was measured on: None (never a stale number) when the sources have
-    changed since, when the file is absent or when the workload is not the one that was profiled."""
-    path = os.path.join(REPO, PMC_FILE)
+def pmc_traffic(kernel, same_workload, pmc_file=None):
+    """HBM-side bytes per launch of `kernel` from the committed PMC passes (separate rocprofv3 --pmc runs, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  A file carries the hash of xmca_amd/csrc it was measured on: None (never a
+    stale number) when the sources have changed since, when the file is absent or when the workload is not the one that was
+    profiled."""
+    path = os.path.join(REPO, pmc_file or PMC_FILE)
     if not same_workload or not os.path.exists(path):
         return None
     try:
@@ -286,7 +288,7 @@ def main():
                             "peak on MI355X); latency-bound by design: T dependent columns, each one exchange across the chip",
                     "traffic": pmc_traffic("trd_resident_kernel", (T, N) == (2920, 10000) and resident),
                     "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at the default workload, "
-                                      "gfx950-corrected, bytes per launch: %s (scripts/r03_profiles.sh), stamped with the hash "
+                                      "gfx950-corrected, bytes per launch: %s (scripts/r04_profiles.sh), stamped with the hash "
                                       "of xmca_amd/csrc; null when the sources differ or for any other workload" % PMC_FILE,
                     "flops_per_launch": flops_trd, "avg_launch_ms": ms_trd, "launches_per_step": trd_calls / args.steps,
                     "share_of_step": trd_ms / args.steps / ms_per_step, "exchange_us_per_column": 1e3 * ms_trd / T,
@@ -298,7 +300,10 @@ def main():
     gram_tf = g["flops"] / (g["kernel_ms"] * 1e-3) / 1e12
     roofline_gemm = {"kernel": "gemm_kernel<f64> (Gram X X^T, v_mfma_f64_16x16x4_f64, upper block triangle)", "bound": "mfma",
                      "achieved": gram_tf, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": gram_tf / F64_MFMA_PEAK_TF,
-                     "traffic": None, "flops_per_launch": g["flops"], "avg_launch_ms": g["kernel_ms"],
+                     "traffic": pmc_traffic("gemm_kernel", (T, N) == (2920, 10000), PMC_GRAM_C2),
+                     "traffic_source": "rocprofv3 --pmc passes of scripts/gram_only.py c2 (the Gram launch alone: field read through "
+                                       "the Infinity Cache + split-K slabs written and read once), bytes per launch: %s" % PMC_GRAM_C2,
+                     "flops_per_launch": g["flops"], "avg_launch_ms": g["kernel_ms"],
                      "product_ms_incl_reduction": g["avg_ms"], "algorithmic_bytes": 8.0 * (T * N + T * T)}
 
     extra = {}
@@ -406,7 +411,9 @@ def main():
                                               "v_mfma_f32_16x16x4_f32, k-slices of <= 16384 products added in float64 inside the "
                                               "launch)", "bound": "mfma",
                                     "achieved": tf5, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf5 / F32_MFMA_PEAK_TF,
-                                    "traffic": None, "flops_per_launch": g5["flops"], "avg_launch_ms": g5["kernel_ms"],
+                                    "traffic": pmc_traffic("gemm_kernel", True, PMC_GRAM_C5),
+                                    "traffic_source": "rocprofv3 --pmc passes of scripts/gram_only.py c5, bytes per launch: %s" % PMC_GRAM_C5,
+                                    "flops_per_launch": g5["flops"], "avg_launch_ms": g5["kernel_ms"],
                                     "product_ms_incl_reduction": g5["avg_ms"], "algorithmic_bytes": 4.0 * T5 * N5 + 8.0 * T5 * T5}
             del h5
         except Exception as e:                                    # noqa: BLE001  (reported, never fatal for the headline)
