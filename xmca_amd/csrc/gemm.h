@@ -192,8 +192,40 @@ static __device__ __forceinline__ int gemm_lane_id() {
   return l;
 }
 
-template <typename TI, typename TO, bool A_KFAST, bool B_NFAST, bool WIDE>
+// X3 (float operands, both contiguous along the contraction: the covariance / Gram product of a float32 field): every float32
+// element is split into three bfloat16 pieces on the way from LDS to the matrix pipe - x = h + m + l, 8 mantissa bits each,
+// see gemm_split3 - and the product runs as six
+// v_mfma_f32_32x32x16_bf16 per tile and 16 contraction indices, a.b ~ hh + (hm + mh) + (mm + hl + lh); the three terms left
+// out are below 2^-23 |a||b|, the rounding of the float32 inputs themselves.  bfloat16 MFMA is 16 x the float32 rate, so
+// the six products cost 3/8 of the v_mfma_f32_16x16x4_f32 path; sums stay float32 in the accumulators with the same
+// 512 / 16 384-product levels.  Same LDS image and staging as the float32 kernel.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f16v_t __attribute__((ext_vector_type(16)));
+typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
+
+// eight floats (k ascending) -> three vectors of eight bfloat16, x = h + m + l up to 2^-25 |x|: h = bf16(x), m = bf16(x - h),
+// l = bf16(x - h - m), each rounded to nearest (v_cvt_pk_bf16_f32: two elements per instruction; the remainders x - h and
+// x - h - m are exact).  Rounding rather than truncating makes the pieces of mixed sign, so the cross terms the product leaves
+// out (m l, l m, l l: <= 2^-24 |a||b| each) are zero-mean and add up like rounding noise instead of a bias.  Per pair of
+// elements: cvt_pk, two unpacks (shift / AND), one packed subtraction - twice - and a last cvt_pk: nine instructions.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ void gemm_split3(const f4_t& x0, const f4_t& x1, u4_t& h, u4_t& m, u4_t& l) {
+  const f2_t x[4] = {f2_t{x0[0], x0[1]}, f2_t{x0[2], x0[3]}, f2_t{x1[0], x1[1]}, f2_t{x1[2], x1[3]}};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const unsigned int hp = __builtin_bit_cast(unsigned int, __builtin_convertvector(x[q], bf16x2_t));
+    h[q] = hp;
+    const f2_t r = x[q] - f2_t{__uint_as_float(hp << 16), __uint_as_float(hp & 0xffff0000u)};
+    const unsigned int mp = __builtin_bit_cast(unsigned int, __builtin_convertvector(r, bf16x2_t));
+    m[q] = mp;
+    const f2_t t = r - f2_t{__uint_as_float(mp << 16), __uint_as_float(mp & 0xffff0000u)};
+    l[q] = __builtin_bit_cast(unsigned int, __builtin_convertvector(t, bf16x2_t));
+  }
+}
+
+template <typename TI, typename TO, bool A_KFAST, bool B_NFAST, bool WIDE, bool X3 = false>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams<TI, TO> p) {
+  static_assert(!X3 || (std::is_same<TI, float>::value && A_KFAST && !B_NFAST && WIDE), "X3: float32, both operands K-fast");
   using M_ = Mfma<TI>;
   using acc_t = typename M_::acc_t;
   using vec_t = typename M_::vec_t;
@@ -225,15 +257,25 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams<TI, TO
   int lane = gemm_lane_id();
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
 
-  acc_t acc[4][4];
-  acc_t wide[WIDE ? 4 : 1][WIDE ? 4 : 1];      // second-level f32 sums (see GEMM_FLUSH_PRODUCTS)
+  acc_t acc[X3 ? 1 : 4][X3 ? 1 : 4];
+  acc_t wide[(WIDE && !X3) ? 4 : 1][(WIDE && !X3) ? 4 : 1];      // second-level f32 sums (see GEMM_FLUSH_PRODUCTS)
+  f16v_t acc3[X3 ? 2 : 1][X3 ? 2 : 1], wide3[X3 ? 2 : 1][X3 ? 2 : 1];   // X3: 2 x 2 tiles of 32 x 32
+  if constexpr (X3) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      acc[i][j] = acc_t{0, 0, 0, 0};
-      if constexpr (WIDE) wide[i][j] = acc_t{0, 0, 0, 0};
-    }
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) { acc3[i][j][g] = 0.f; wide3[i][j][g] = 0.f; }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[i][j] = acc_t{0, 0, 0, 0};
+        if constexpr (WIDE) wide[i][j] = acc_t{0, 0, 0, 0};
+      }
+  }
 
   // ---- staging ----
   // fast path (LDS-DMA): wave w issues the instructions q = 4 w + j (j = 0..3) of each operand; instruction q fills the
@@ -293,27 +335,72 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams<TI, TO
       *reinterpret_cast<vec_t*>(smem + s * 2 * SB + SB + o) = x;
     }
   };
-  int fa0 = OA::frag_base(wm, lane), fb0 = OB::frag_base(wn, lane) + SB;
-  frag_t af[2][4], bf[2][4];
-  auto read_frags = [&](const char* sb, int q, frag_t (&a)[4], frag_t (&b)[4]) {
+  // X3 fragments: lane (i = lane & 31, kk = lane >> 5) reads the 8 floats k = 16 q + 8 kk ... + 7 of row w0 + 32 t + i - two
+  // neighbouring 16-byte chunks (c, c ^ 1 after the swizzle), conflict-free like the reads of the float32 path
+  int fa0 = X3 ? (wm + (lane & 31)) * 128 + (((2 * (lane >> 5)) ^ (((lane & 31) >> 1) & 7)) << 4) : OA::frag_base(wm, lane);
+  int fb0 = (X3 ? (wn + (lane & 31)) * 128 + (((2 * (lane >> 5)) ^ (((lane & 31) >> 1) & 7)) << 4) : OB::frag_base(wn, lane)) + SB;
+  constexpr int NFR = X3 ? 1 : 4, NQ = X3 ? 2 : NPH;        // (X3: one phase = 16 contraction indices)
+  frag_t af[X3 ? 1 : 2][NFR], bf[X3 ? 1 : 2][NFR];
+  f4_t ar3[X3 ? 2 : 1][2], br3[X3 ? 2 : 1][2];              // X3: raw floats of the NEXT phase
+  auto read_frags3 = [&](const char* sb, int q) {
+    asm("" : "+v"(fa0), "+v"(fb0));
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int oa = (fa0 ^ (q << 6)) + t * 4096, ob = (fb0 ^ (q << 6)) + t * 4096;
+      ar3[t][0] = *reinterpret_cast<const f4_t*>(sb + oa);
+      ar3[t][1] = *reinterpret_cast<const f4_t*>(sb + (oa ^ 16));
+      br3[t][0] = *reinterpret_cast<const f4_t*>(sb + ob);
+      br3[t][1] = *reinterpret_cast<const f4_t*>(sb + (ob ^ 16));
+    }
+  };
+  u4_t ah[X3 ? 2 : 1], am[X3 ? 2 : 1], al[X3 ? 2 : 1], bh[X3 ? 2 : 1], bm3[X3 ? 2 : 1], bl[X3 ? 2 : 1];
+  auto split3 = [&]() {       // raw floats of this phase -> bfloat16 planes; ar3 / br3 are free for the next phase's reads afterwards
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      gemm_split3(ar3[t][0], ar3[t][1], ah[t], am[t], al[t]);
+      gemm_split3(br3[t][0], br3[t][1], bh[t], bm3[t], bl[t]);
+    }
+  };
+  auto mma3 = [&]() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    auto B8 = [](const u4_t& v) { return __builtin_bit_cast(bf16x8_t, v); };
+    // term by term over the four tiles: consecutive MFMAs never touch the same accumulator (small terms first)
+#define XMCA_X3_TERM(P, Q)                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                              \
+        acc3[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B8(P[i]), B8(Q[j]), acc3[i][j], 0, 0, 0);
+    XMCA_X3_TERM(al, bh)
+    XMCA_X3_TERM(ah, bl)
+    XMCA_X3_TERM(am, bm3)
+    XMCA_X3_TERM(am, bh)
+    XMCA_X3_TERM(ah, bm3)
+    XMCA_X3_TERM(ah, bh)
+#undef XMCA_X3_TERM
+#endif
+  };
+  auto read_frags = [&](const char* sb, int q, frag_t (&a)[NFR], frag_t (&b)[NFR]) {
     // (the per-phase XORs of the two base addresses are one instruction each; hoisted out of the loop they would occupy
     // up to six more registers for its whole duration - the empty asm makes the bases look freshly written)
 #ifndef GEMM_NO_LAUNDER
     asm("" : "+v"(fa0), "+v"(fb0));
 #endif
+    if constexpr (!X3) {
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      a[f] = *reinterpret_cast<const frag_t*>(sb + OA::frag_addr(fa0, q, f));
-      b[f] = *reinterpret_cast<const frag_t*>(sb + OB::frag_addr(fb0, q, f));
+      for (int f = 0; f < 4; ++f) {
+        a[f] = *reinterpret_cast<const frag_t*>(sb + OA::frag_addr(fa0, q, f));
+        b[f] = *reinterpret_cast<const frag_t*>(sb + OB::frag_addr(fb0, q, f));
+      }
     }
   };
-  auto mfmas = [&](const frag_t (&a)[4], const frag_t (&b)[4]) {
+  auto mfmas = [&](const frag_t (&a)[NFR], const frag_t (&b)[NFR]) {
+    if constexpr (!X3) {
 #pragma unroll
-    for (int e = 0; e < 2; ++e)
+      for (int e = 0; e < 2; ++e)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = M_::mma(OA::value(a, e, i), OB::value(b, e, j), acc[i][j]);
+          for (int j = 0; j < 4; ++j) acc[i][j] = M_::mma(OA::value(a, e, i), OB::value(b, e, j), acc[i][j]);
+    }
   };
 
   const int nkt = (kend - kbeg + BK - 1) / BK;
@@ -326,7 +413,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams<TI, TO
   if (ragged && kend == p.K && nfull > 0 && nfull * BK == kend - kbeg) --nfull;
   constexpr int FLUSH_TILES = GEMM_FLUSH_PRODUCTS / BK;
   auto flush = [&](int kt) {
-    if constexpr (WIDE) {
+    if constexpr (X3) {
+      if ((kt % FLUSH_TILES) == FLUSH_TILES - 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { wide3[i][j][g] += acc3[i][j][g]; acc3[i][j][g] = 0.f; }
+      }
+    } else if constexpr (WIDE) {
       if ((kt % FLUSH_TILES) == FLUSH_TILES - 1) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -343,9 +439,27 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams<TI, TO
     stage_fast(kbeg, 0);
     __syncthreads();
     if (nfull > 1) stage_fast(kbeg + BK, 1);
-    read_frags(smem, 0, af[0], bf[0]);
+    if constexpr (X3) read_frags3(smem, 0);
+    else read_frags(smem, 0, af[0], bf[0]);
   }
-  for (int kt = 0; kt < nfull; ++kt) {
+  if constexpr (X3) {
+    // the same pipeline with the split in front of the next phase's reads: split(q), reads(q + 1), six MFMAs per tile
+    for (int kt = 0; kt < nfull; ++kt) {
+      const char* sb = smem + (kt & 1) * 2 * SB;
+      split3();
+      read_frags3(sb, 1);
+      mma3();
+      split3();
+      if (kt + 1 < nfull) {
+        __syncthreads();
+        if (kt + 2 < nfull) stage_fast(kbeg + (kt + 2) * BK, kt & 1);
+        read_frags3(smem + ((kt + 1) & 1) * 2 * SB, 0);
+      }
+      mma3();
+      flush(kt);
+    }
+  }
+  for (int kt = 0; !X3 && kt < nfull; ++kt) {
     const char* sb = smem + (kt & 1) * 2 * SB;
 #pragma unroll
     for (int q = 0; q < NPH; ++q) {
@@ -371,46 +485,49 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams<TI, TO
     __syncthreads();
     stage_slow(kbeg + kt * BK, 0, tid);
     __syncthreads();
+    if constexpr (X3) {
 #pragma unroll
-    for (int q = 0; q < NPH; ++q) {
-      read_frags(smem, q, af[0], bf[0]);
-      mfmas(af[0], bf[0]);
+      for (int q = 0; q < 2; ++q) {
+        read_frags3(smem, q);
+        split3();
+        mma3();
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NPH; ++q) {
+        read_frags(smem, q, af[0], bf[0]);
+        mfmas(af[0], bf[0]);
+      }
     }
     flush(kt);
   }
 
-  // ---- totals of this slice as doubles ----
-  d4_t tot[4][4];
+  // ---- totals of this slice as doubles, by accumulator register r = 0..63 of the lane ----
+  //   native: r = (i * 4 + j) * 4 + q  (MFMA tile (i, j) of 16 x 16, register q);  X3: r = (i * 2 + j) * 16 + g  (32 x 32 tiles)
+  d2_t tot[32];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        double v = (double)acc[i][j][r];
-        if constexpr (WIDE) v += (double)wide[i][j][r];
-        tot[i][j][r] = v;
-      }
+  for (int r = 0; r < 64; ++r) {
+    double v;
+    if constexpr (X3) v = (double)acc3[r >> 5][(r >> 4) & 1][r & 15] + (double)wide3[r >> 5][(r >> 4) & 1][r & 15];
+    else {
+      v = (double)acc[r >> 4][(r >> 2) & 3][r & 3];
+      if constexpr (WIDE) v += (double)wide[r >> 4][(r >> 2) & 3][r & 3];
+    }
+    tot[r >> 1][r & 1] = v;
+  }
 
   if (p.splits > 1) {
-    // publish this slice's sums in register order - element pair (i, j, h) of thread tid at ((i * 4 + j) * 2 + h) * 256 + tid,
-    // 1 KB per store instruction - with write-through (sc1) 16-byte stores: no release fence (the L2 write-back of a fence
-    // costs microseconds with 128 KB freshly dirtied per workgroup: MI355X_MICROARCH.md "publish-large"), the drained
-    // stores + barrier + relaxed ticket are the publication (cdna_hip_programming.md 5, sc1 form of the split-K hand-off)
+    // publish this slice's sums in register order - register pair h of thread tid at h * 256 + tid, 1 KB per store instruction -
+    // with write-through (sc1) 16-byte stores: no release fence (the L2 write-back of a fence costs microseconds with
+    // 128 KB freshly dirtied per workgroup: MI355X_MICROARCH.md "publish-large"), the drained stores + barrier + relaxed
+    // ticket are the publication (cdna_hip_programming.md 5, sc1 form of the split-K hand-off)
     double* __restrict__ mine = p.slabs + ((size_t)split * p.n_tiles + tile) * (size_t)(GEMM_BM * GEMM_BN);
 #if defined(__HIP_DEVICE_COMPILE__)
     {
-      typedef unsigned u4_t __attribute__((ext_vector_type(4)));
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(mine, 0, GEMM_BM * GEMM_BN * 8, 0x00020000);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const d2_t v{tot[i][j][2 * h], tot[i][j][2 * h + 1]};
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rs, tid * 16, ((i * 4 + j) * 2 + h) * 4096, /*sc1*/ 16);
-          }
+      for (int h = 0; h < 32; ++h)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, tot[h]), rs, tid * 16, h * 4096, /*sc1*/ 16);
     }
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -430,21 +547,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams<TI, TO
     // the last arriver: slabs of all slices in slice order (its own comes back from memory too: same bits for every
     // arrival order)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) tot[i][j] = d4_t{0, 0, 0, 0};
+    for (int h = 0; h < 32; ++h) tot[h] = d2_t{0, 0};
     for (int z = 0; z < p.splits; ++z) {
       const d2_t* __restrict__ sl = reinterpret_cast<const d2_t*>(p.slabs + ((size_t)z * p.n_tiles + tile) * (size_t)(GEMM_BM * GEMM_BN));
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int h0 = 0; h0 < 32; h0 += 8) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const d2_t v = sl[((i * 4 + j) * 2 + h) * GEMM_THREADS + tid];
-            tot[i][j][2 * h] += v[0];
-            tot[i][j][2 * h + 1] += v[1];
-          }
+        for (int h = h0; h < h0 + 8; ++h) tot[h] += sl[h * GEMM_THREADS + tid];
         asm volatile("" ::: "memory");     // eight loads in flight per lane, not thirty-two: the totals already take 128 registers
       }
     }
@@ -452,26 +561,33 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams<TI, TO
 
   // ---- epilogue ----
   const bool offdiag = (bm != bn);
-  const int l15 = lane & 15;
   TO* __restrict__ C = p.C;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = bm0 + wm + OA::index(i, M_::row(lane, r));
-        const int col = bn0 + wn + OB::index(j, l15);
-        if (row < p.M && col < p.N) {
-          double v = tot[i][j][r] * p.alpha;
-          if (p.row_scale) v *= p.row_scale[row];
-          if (p.col_scale) v *= p.col_scale[col];
-          const int64_t o = (int64_t)row * p.ldc + col;
-          if (p.beta != 0.0) v += p.beta * (double)C[o];
-          C[o] = (TO)v;
-          if (p.mirror != 0 && offdiag) C[(int64_t)col * p.ldc + row] = (TO)(p.mirror > 0 ? v : -v);
-        }
-      }
+  for (int r = 0; r < 64; ++r) {
+    int rin, cin;                          // position inside the 64 x 64 wave tile
+    if constexpr (X3) {                    // C/D layout of the 32 x 32 MFMA: col = lane & 31, row = (g & 3) + 8 (g >> 2) + 4 (lane >> 5)
+      const int g = r & 15;
+      rin = 32 * (r >> 5) + (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5);
+      cin = 32 * ((r >> 4) & 1) + (lane & 31);
+    } else {
+      rin = OA::index(r >> 4, M_::row(lane, r & 3));
+      cin = OB::index((r >> 2) & 3, lane & 15);
+    }
+    const int row = bm0 + wm + rin, col = bn0 + wn + cin;
+    // symmetric results (mirror = +1): inside a DIAGONAL tile only the upper triangle is stored and mirrored as well - the two
+    // halves are computed by different lanes, and in the X3 form with the three-way terms in a different order, so they agree
+    // to rounding only; the matrix that leaves the kernel is symmetric bit for bit
+    const bool sym_diag = p.mirror > 0 && !offdiag;
+    if (row < p.M && col < p.N && !(sym_diag && col < row)) {
+      double v = tot[r >> 1][r & 1] * p.alpha;
+      if (p.row_scale) v *= p.row_scale[row];
+      if (p.col_scale) v *= p.col_scale[col];
+      const int64_t o = (int64_t)row * p.ldc + col;
+      if (p.beta != 0.0) v += p.beta * (double)C[o];
+      C[o] = (TO)v;
+      if ((p.mirror != 0 && offdiag) || (sym_diag && col > row)) C[(int64_t)col * p.ldc + row] = (TO)(p.mirror > 0 ? v : -v);
+    }
+  }
 }
 
 struct GemmOpts {
@@ -534,9 +650,23 @@ struct GemmWorkspace {
   }
 };
 
+// float32 products with both operands contiguous along the contraction (Gram / covariance of a float32 field) by three-way
+// bfloat16 splitting (X3 in the kernel): on unless XMCA_GEMM_BF16X3=0
+static inline bool gemm_x3_enabled() {
+  static const bool on = [] { const char* e = std::getenv("XMCA_GEMM_BF16X3"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 template <typename TI, typename TO, bool WIDE>
 static void launch_gemm_variant(hipStream_t st, const GemmParams<TI, TO>& p, bool a_kfast, bool b_nfast) {
   dim3 grid(p.n_wg), block(GEMM_THREADS);
+  if constexpr (std::is_same<TI, float>::value) {
+    if (a_kfast && !b_nfast && gemm_x3_enabled()) {
+      hipLaunchKernelGGL((gemm_kernel<TI, TO, true, false, WIDE, true>), grid, block, 0, st, p);
+      XMCA_HIP(hipGetLastError());
+      return;
+    }
+  }
   if (a_kfast && b_nfast) hipLaunchKernelGGL((gemm_kernel<TI, TO, true, true, WIDE>), grid, block, 0, st, p);
   else if (a_kfast && !b_nfast) hipLaunchKernelGGL((gemm_kernel<TI, TO, true, false, WIDE>), grid, block, 0, st, p);
   else if (!a_kfast && b_nfast) hipLaunchKernelGGL((gemm_kernel<TI, TO, false, true, WIDE>), grid, block, 0, st, p);
