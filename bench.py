@@ -407,9 +407,14 @@ def main():
             h5.bench_gram(0, 1)
             g5 = h5.bench_gram(0, 3)
             tf5 = g5["flops"] / (g5["kernel_ms"] * 1e-3) / 1e12
+            x3 = os.environ.get("XMCA_GEMM_BF16X3", "1") != "0"
             extra["roofline_c5"] = {"kernel": "gemm_kernel<f32> (Gram X X^T of the resident T=1200 x N=1036800 float32 field, "
-                                              "v_mfma_f32_16x16x4_f32, k-slices of <= 16384 products added in float64 inside the "
-                                              "launch)", "bound": "mfma",
+                                              + ("each float32 split into three bfloat16 pieces in registers, six "
+                                                 "v_mfma_f32_32x32x16_bf16 terms per product" if x3 else "v_mfma_f32_16x16x4_f32")
+                                              + ", k-slices of <= 16384 products added in float64 inside the launch; achieved / "
+                                              "peak count the USEFUL float32 flops against the float32 MFMA peak)",
+                                    "bound": "mfma", "bf16x3": x3,
+                                    "mfma_flops_issued_per_launch": g5["flops"] * (6.0 if x3 else 1.0),
                                     "achieved": tf5, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf5 / F32_MFMA_PEAK_TF,
                                     "traffic": pmc_traffic("gemm_kernel", True, PMC_GRAM_C5),
                                     "traffic_source": "rocprofv3 --pmc passes of scripts/gram_only.py c5, bytes per launch: %s" % PMC_GRAM_C5,

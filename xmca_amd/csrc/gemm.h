@@ -1,10 +1,11 @@
 // MFMA GEMM for gfx950: C[MxN] = alpha * rs[m] * cs[n] * op(A) * op(B) + beta * C          (round 4: rewritten)
 //
-// * f64 operands -> v_mfma_f64_16x16x4_f64, f32 operands -> v_mfma_f32_16x16x4_f32 (exact f32, flushed into f64 side
-//   accumulators every 512 products so that long contractions keep f64-class accumulation error: "WIDE").
+// * f64 operands -> v_mfma_f64_16x16x4_f64, f32 operands -> v_mfma_f32_16x16x4_f32 (exact f32) with three levels of
+//   accumulation ("WIDE", see GEMM_FLUSH_PRODUCTS) - or, for float32 products with both operands contiguous along the
+//   contraction, six v_mfma_f32_32x32x16_bf16 on three-way bfloat16 pieces of the operands ("X3").
 // * 128 x 128 block tile, 256 threads = 4 waves (2 x 2), each wave a 64 x 64 tile = 4 x 4 MFMA tiles; two workgroups per CU
-//   (one wave of each on every SIMD, 256 registers per lane each: accumulators + side accumulators + two sets of fragments
-//   fit, no scratch).
+//   (one wave of each on every SIMD, 256 registers per lane each: accumulators + second-level sums + two sets of fragments
+//   fit, no scratch in any instantiation).
 // * operands go global -> LDS by LDS-DMA (`global_load_lds`, 16 bytes per lane, no staging registers) into two stages of
 //   16 KB per operand (BK = 16 doubles / 32 floats = 128 bytes per row).  ONE barrier per k-tile, placed before the LAST
 //   phase of a tile: behind it the DMA of k-tile t + 2 is issued into the stage everybody has finished reading, the first
@@ -26,8 +27,9 @@
 //   and resets the counter (cdna_hip_programming.md 5, "in-launch split-K reduction", sc1 form).  No reduce kernel.
 // * the (slice, tile) list is dealt to the 8 XCDs in contiguous ranges (workgroup b runs on XCD b % 8) and tiles are
 //   enumerated in 8 x 8 super-blocks, so the workgroups sharing one L2 work on neighbouring tiles of the same k-slice.
-// * unaligned operands (leading dimension or base not a multiple of 16 bytes) and the last, partial k-tile are staged
-//   through registers with predicated element loads (zero filled) into the same LDS image.
+// * the LDS-DMA needs no alignment beyond the element's (odd leading dimensions, odd bases: same rate); only the last,
+//   partial k-tile (and operands whose tile offsets do not fit 32 bits) is staged through registers with predicated element
+//   loads (zero filled) into the same LDS image.
 //
 // Reference call sites this replaces: numpy `@` / gesdd inner products of xmca/array.py:479, :552-566 and :580-584
 // (see DESIGN.md for the formulation).
@@ -108,7 +110,7 @@ struct GemmParams {
   int n_tiles;              // block tiles per slice (upper triangle only when upper_only)
   int n_wg;                 // n_tiles * splits
   const int* tile_map;      // n_tiles packed (bm << 16 | bn) in super-block order
-  int vec_a, vec_b;         // 16-byte LDS-DMA allowed (base and leading dimension aligned, tile offsets fit 32 bits)
+  int vec_a, vec_b;         // LDS-DMA allowed (element-aligned base, tile offsets fit 32 bits)
   double* slabs;            // split-K: [splits][n_tiles][128 * 128] raw sums in register order
   int* counters;            // split-K: arrival tickets, one per tile, zero between launches
 };
