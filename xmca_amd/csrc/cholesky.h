@@ -233,9 +233,11 @@ __global__ void chol_minmax_diag_kernel(const double* __restrict__ Gr, int64_t l
 template <typename TI>
 void cgemm(hipStream_t st, GemmWorkspace& ws, const TI* Ar, const TI* Ai, int64_t lda, bool a_kfast, bool conjA, const TI* Br,
            const TI* Bi, int64_t ldb, bool b_nfast, bool conjB, double* Cr, double* Ci, int64_t ldc, int M, int N, int K,
-           double alpha, const double* row_scale, const double* col_scale, bool herm, double beta0 = 0.0) {
-  // beta0: C = ... + beta0 * C (both planes)
+           double alpha, const double* row_scale, const double* col_scale, bool herm, double beta0 = 0.0,
+           const GemmTileList* tiles = nullptr) {
+  // beta0: C = ... + beta0 * C (both planes);  tiles: block-sparse product (gemm.h GemmTileList)
   GemmOpts o;
+  o.tiles = tiles;
   o.a_kfast = a_kfast;
   o.b_nfast = b_nfast;
   o.row_scale = row_scale;

@@ -110,6 +110,7 @@ struct GemmParams {
   int n_tiles;              // block tiles per slice (upper triangle only when upper_only)
   int n_wg;                 // n_tiles * splits
   const int* tile_map;      // n_tiles packed (bm << 16 | bn) in super-block order
+  const int* tile_k;        // nullable: per tile the contraction range [tile_k[2 t], tile_k[2 t + 1]) (GemmTileList), else [0, K)
   int vec_a, vec_b;         // LDS-DMA allowed (element-aligned base, tile offsets fit 32 bits)
   double* slabs;            // split-K: [splits][n_tiles][128 * 128] raw sums in register order
   int* counters;            // split-K: arrival tickets, one per tile, zero between launches
@@ -249,8 +250,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams<TI, TO
   const int packed = p.tile_map[tile];
   const int bm = packed >> 16, bn = packed & 0xffff;
   const int bm0 = bm * GEMM_BM, bn0 = bn * GEMM_BN;
-  const int kbeg = split * p.k_chunk;
-  const int kend = min(p.K, kbeg + p.k_chunk);
+  int kbeg, kend;
+  if (p.tile_k) {             // block-sparse products: the tile's own contraction range, cut into p.splits slices
+    const int kb = p.tile_k[2 * tile], ke = p.tile_k[2 * tile + 1];
+    const int kc = ((ke - kb + GemmK<TI>::BK * p.splits - 1) / (GemmK<TI>::BK * p.splits)) * GemmK<TI>::BK;
+    kbeg = kb + split * kc;
+    kend = max(kbeg, min(ke, kbeg + kc));
+  } else {
+    kbeg = split * p.k_chunk;
+    kend = min(p.K, kbeg + p.k_chunk);
+  }
 
   // Nothing derived from the lane index has to stay in a register across the main loop except the two fragment addresses
   // and the four DMA offsets: the f32 build has 64 + 128 accumulator registers and no room for bystanders, so the lane
@@ -592,6 +601,24 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams<TI, TO
   }
 }
 
+// A caller-made list of block tiles, each with its own contraction range: block-sparse products (the compact-WY
+// precomputation of tridiag_vec.h) as ONE launch.  K of the call stays the extent of the operands along the contraction.
+struct GemmTileList {
+  DevBuf<int> map;       // (bm << 16) | bn
+  DevBuf<int> krange;    // [k0, k1) per tile, k0 a multiple of 16
+  int n = 0;
+  int klen = 0;          // longest range (split heuristic)
+  void upload(hipStream_t st, const std::vector<int>& tiles, const std::vector<int>& kr) {
+    n = (int)tiles.size();
+    klen = 0;
+    for (int t = 0; t < n; ++t) klen = std::max(klen, kr[2 * t + 1] - kr[2 * t]);
+    if (n == 0) return;
+    XMCA_HIP(hipMemcpyAsync(map.ensure(tiles.size()), tiles.data(), sizeof(int) * tiles.size(), hipMemcpyHostToDevice, st));
+    XMCA_HIP(hipMemcpyAsync(krange.ensure(kr.size()), kr.data(), sizeof(int) * kr.size(), hipMemcpyHostToDevice, st));
+    XMCA_HIP(hipStreamSynchronize(st));
+  }
+};
+
 struct GemmOpts {
   bool a_kfast = true;   // A(m,k) = A[m*lda + k]
   bool b_nfast = true;   // B(k,n) = B[k*ldb + n]
@@ -601,6 +628,7 @@ struct GemmOpts {
   bool upper_only = false;
   int mirror = 0;
   int force_splits = 0;  // 0 = heuristic
+  const GemmTileList* tiles = nullptr;   // block-sparse: only these tiles, each over its own contraction range (no upper_only / mirror)
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;   // optional: recorded around the MFMA kernel launch alone
 };
 
@@ -704,23 +732,33 @@ void gemm(hipStream_t st, GemmWorkspace& ws, const TI* A, int64_t lda, const TI*
   XMCA_CHECK(!o.upper_only || M == N, XMCA_ERR_INVALID, "gemm: upper_only needs a square result");
   constexpr int BK = GemmK<TI>::BK, CE = GemmK<TI>::CE;
   const int tm = ceil_div(M, GEMM_BM), tn = ceil_div(N, GEMM_BN);
-  const int64_t tiles = o.upper_only ? (int64_t)tm * (tm + 1) / 2 : (int64_t)tm * tn;
-  const int nkt = ceil_div(K, BK);
   constexpr bool WIDE = std::is_same<TI, float>::value;
+  const GemmTileList* list = o.tiles;
+  XMCA_CHECK(!list || (!o.upper_only && o.mirror == 0 && !WIDE), XMCA_ERR_INVALID, "gemm: tile lists are plain float64 products");
+  if (list && list->n == 0) return;
+  const int64_t tiles = list ? list->n : o.upper_only ? (int64_t)tm * (tm + 1) / 2 : (int64_t)tm * tn;
+  const int klen = list ? list->klen : K;
+  const int nkt = ceil_div(klen, BK);
   int splits = o.force_splits > 0 ? o.force_splits : gemm_choose_splits(tiles, nkt, ws.cus());
   if (WIDE) splits = std::max(splits, ceil_div(K, GEMM_SLICE_PRODUCTS));
-  const GemmWorkspace::Map& map = ws.tile_map(st, tm, tn, o.upper_only);
-  XMCA_CHECK(map.n == tiles && tm < 65536 && tn < 65536, XMCA_ERR_INVALID, "gemm: tile map mismatch");
+  const int* map_dev = nullptr;
+  if (list) {
+    map_dev = list->map.get();
+  } else {
+    const GemmWorkspace::Map& map = ws.tile_map(st, tm, tn, o.upper_only);
+    XMCA_CHECK(map.n == tiles && tm < 65536 && tn < 65536, XMCA_ERR_INVALID, "gemm: tile map mismatch");
+    map_dev = map.dev.get();
+  }
   // LDS-DMA: tile-relative byte offsets must fit 32 bits, elements naturally aligned (anything else: register path)
   const int vec_a = lda * (int64_t)sizeof(TI) * 128 < ((int64_t)1 << 32) && reinterpret_cast<uintptr_t>(A) % sizeof(TI) == 0;
   const int vec_b = ldb * (int64_t)sizeof(TI) * 128 < ((int64_t)1 << 32) && reinterpret_cast<uintptr_t>(B) % sizeof(TI) == 0;
-  int k_chunk = K > 0 ? K : 1;
+  int k_chunk = klen > 0 ? klen : 1;
   if (splits > 1) {
     k_chunk = ceil_div(nkt, splits) * BK;
     if (WIDE) k_chunk = std::min(k_chunk, GEMM_SLICE_PRODUCTS);
-    splits = ceil_div(K, k_chunk);
+    splits = ceil_div(klen, k_chunk);
   }
-  if (splits < 1 || K <= 0) splits = 1;
+  if (splits < 1 || klen <= 0) splits = 1;
   XMCA_CHECK(tiles * splits < (int64_t)1 << 31, XMCA_ERR_INVALID, "gemm: too many workgroups");
   double* slabs = nullptr;
   int* counters = nullptr;
@@ -729,7 +767,8 @@ void gemm(hipStream_t st, GemmWorkspace& ws, const TI* A, int64_t lda, const TI*
     counters = ws.tickets(st, (size_t)tiles);
   }
   GemmParams<TI, TO> p{A, B, C, M, N, K, lda, ldb, ldc, o.alpha, o.beta, o.row_scale, o.col_scale, o.upper_only ? 1 : 0, o.mirror,
-                       k_chunk, splits, (int)tiles, (int)(tiles * splits), map.dev.get(), vec_a, vec_b, slabs, counters};
+                       k_chunk, splits, (int)tiles, (int)(tiles * splits), map_dev, list ? list->krange.get() : nullptr, vec_a, vec_b,
+                       slabs, counters};
   if (o.ev_begin) XMCA_HIP(hipEventRecord(o.ev_begin, st));
   launch_gemm_variant<TI, TO, WIDE>(st, p, o.a_kfast, o.b_nfast);
   if (o.ev_end) XMCA_HIP(hipEventRecord(o.ev_end, st));

@@ -5,11 +5,13 @@
 //      z(i+1) = -(e_i / D-_{i+1}) z(i) downwards (Parlett & Dhillon; LAPACK dlar1v without the RRR shifts).  With an
 //      eigenvalue accurate to eps ||T|| the residual is eps ||T||; vectors of close eigenvalues are orthogonal only to
 //      eps ||T|| / gap - the clean-up below restores that;
-//   2. back-transformation with blocks of 128 reflectors in compact WY form, Z -= V (T (V^H Z)), the two tall products MFMA
-//      GEMMs.  T is never formed: its inverse is explicit, T^{-1} = striu(V^H V) + diag(1 / tau) (from T^{-1} + T^{-H} =
-//      V^H V), so T W is a back substitution per column (trd_wy_solve_kernel), and V^H V comes out of the same product as
-//      W = V^H Z (the reflectors ride along as 128 extra columns of Z); the 128 x 128 system is solved in two halves of 64
-//      with one small product in between;
+//   2. back-transformation with super-blocks of 512 reflectors in compact WY form, Z -= V (T (V^H Z)): two MFMA GEMMs per
+//      super-block, X = (T V^H) Z and Z -= V X.  T depends on the reflectors alone and is built for ALL super-blocks ahead
+//      of the loop in a handful of block-sparse launches (gemm.h GemmTileList): with N = I + diag(tau) striu(V^H V),
+//      T = N^{-1} diag(tau) (from T^{-1} + T^{-H} = V^H V; valid for tau = 0 as well); the 64 x 64 diagonal blocks of T by
+//      back substitution (trd_wy_tinv_kernel, one thread per column), then T12 = -T11 S12 T22 level by level (64 -> 128 ->
+//      256 -> 512), two launches per level, and T V^H in one more.  (Rounds 2-3 solved T^{-1} X = W per block of 128 with a
+//      thread per column of Z, between the two GEMMs: 23 x 230 us at n = 2920 against 6 x ~200 us + 0.3 ms now.)
 //   3. S = Z^H Z; max |S - I| decides: <= 0.3 -> one or two Newton-Schulz steps Z <- Z (3/2 I - 1/2 S) (the last one
 //      written as (3/2 I - 1/2 S)(rows reversed) Z^H, i.e. straight into the caller's layout: row i = conj(u_i), eigenvalues
 //      descending); otherwise (clusters the twisted vectors cannot resolve: repeated eigenvalues, exact null spaces of
@@ -21,10 +23,18 @@
 
 namespace xmca {
 
+// value of lane `u` (uniform) for every lane: the tridiagonal's entries reach the recurrences below as one coalesced load per
+// 64 rows and a v_readlane pair per row - an s_load per row (what `e[i]` with a uniform i compiles to) stalls every step of a
+// dependent chain on the scalar cache (s_waitcnt lgkmcnt(0) inside the recurrence: 1.6 ms at n = 2920 instead of 0.9)
+__device__ __forceinline__ double trd_lane_value(double v, int u) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), u), hi = __builtin_amdgcn_readlane(__double2hiint(v), u);
+  return __hiloint2double(hi, lo);
+}
+
 // Yt[i * ldy + k] = component i of the eigenvector of eigenvalue k (ascending);  W: work plane of the same shape.
 // 128 threads per 64 eigenvalues: the forward (D+) and the backward (D-) factorisation are independent recurrences and run
 // in the two waves side by side; so do the two halves of the vector (upwards / downwards from the twist index) and of the
-// final scaling.  Every loop requests 32 elements ahead of the recurrence (they are memory-latency bound otherwise).
+// final scaling.  Every loop requests its operands one chunk (64 rows of d / e, 32 rows of the planes) ahead of the recurrence.
 __global__ __launch_bounds__(128) void trd_twisted_kernel(const double* __restrict__ d, const double* __restrict__ e, int n,
                                                          const double* __restrict__ lam, double* __restrict__ W, double* __restrict__ Yt,
                                                          int64_t ldy) {
@@ -37,39 +47,70 @@ __global__ __launch_bounds__(128) void trd_twisted_kernel(const double* __restri
   if (n == 1) { if (live && half == 0) Yt[k] = 1.0; return; }
   constexpr int B = 32;
   double emax = 0.0;
-  for (int i = 0; i < n - 1; ++i) emax = fmax(emax, fabs(e[i]));
+  for (int i = lane; i < n - 1; i += 64) emax = fmax(emax, fabs(e[i]));
+  for (int o = 32; o > 0; o >>= 1) emax = fmax(emax, __shfl_xor(emax, o));
   const double piv = 2.3e-308 * fmax(1.0, emax * emax) * 1e20 + 1e-300;
   if (half == 0) {
-    // forward: D+ into Yt
+    // forward: D+ into Yt.  Row i0 + u of the chunk: lane u holds e[i0 + u] and d[i0 + u + 1]
     double dp = d[0] - l;
-    for (int i = 0; i < n - 1; ++i) {
-      if (!(fabs(dp) >= piv)) dp = dp < 0.0 ? -piv : piv;
-      if (live) Yt[(int64_t)i * ldy + k] = dp;
-      const double ei = e[i];
-      dp = (d[i + 1] - l) - (ei * trd_rcp(dp)) * ei;
+    auto chunk = [&](int i0) { const int i = i0 + lane < n - 1 ? i0 + lane : n - 2; return i; };
+    double ev = e[chunk(0)], dv = d[chunk(0) + 1];
+    for (int i0 = 0; i0 < n - 1; i0 += 64) {
+      const int nx = i0 + 64 < n - 1 ? i0 + 64 : i0;
+      const double ev_n = e[chunk(nx)], dv_n = d[chunk(nx) + 1];
+      const int cnt = n - 1 - i0 < 64 ? n - 1 - i0 : 64;
+      auto step = [&](int u) {
+        if (!(fabs(dp) >= piv)) dp = dp < 0.0 ? -piv : piv;
+        if (live) Yt[(int64_t)(i0 + u) * ldy + k] = dp;
+        const double ei = trd_lane_value(ev, u);
+        dp = (trd_lane_value(dv, u) - l) - (ei * trd_rcp(dp)) * ei;
+      };
+      if (cnt == 64) {
+#pragma unroll
+        for (int u = 0; u < 64; ++u) step(u);
+      } else {
+        for (int u = 0; u < cnt; ++u) step(u);
+      }
+      ev = ev_n; dv = dv_n;
     }
     if (!(fabs(dp) >= piv)) dp = dp < 0.0 ? -piv : piv;
     if (live) Yt[(int64_t)(n - 1) * ldy + k] = dp;
   } else {
-    // backward: D- into W
+    // backward: D- into W.  Row i0 - u of the chunk (i0 downwards from n - 2): lane u holds e[i0 - u] and d[i0 - u]
     double dm = d[n - 1] - l;
     if (!(fabs(dm) >= piv)) dm = dm < 0.0 ? -piv : piv;
     if (live) W[(int64_t)(n - 1) * ldy + k] = dm;
-    for (int i = n - 2; i >= 0; --i) {
-      const double ei = e[i];
-      dm = (d[i] - l) - (ei * trd_rcp(dm)) * ei;
-      if (!(fabs(dm) >= piv)) dm = dm < 0.0 ? -piv : piv;
-      if (live) W[(int64_t)i * ldy + k] = dm;
+    auto chunk = [&](int i0) { const int i = i0 - lane >= 0 ? i0 - lane : 0; return i; };
+    double ev = e[chunk(n - 2)], dv = d[chunk(n - 2)];
+    for (int i0 = n - 2; i0 >= 0; i0 -= 64) {
+      const int nx = i0 - 64 >= 0 ? i0 - 64 : i0;
+      const double ev_n = e[chunk(nx)], dv_n = d[chunk(nx)];
+      const int cnt = i0 + 1 < 64 ? i0 + 1 : 64;
+      auto step = [&](int u) {
+        const double ei = trd_lane_value(ev, u);
+        dm = (trd_lane_value(dv, u) - l) - (ei * trd_rcp(dm)) * ei;
+        if (!(fabs(dm) >= piv)) dm = dm < 0.0 ? -piv : piv;
+        if (live) W[(int64_t)(i0 - u) * ldy + k] = dm;
+      };
+      if (cnt == 64) {
+#pragma unroll
+        for (int u = 0; u < 64; ++u) step(u);
+      } else {
+        for (int u = 0; u < cnt; ++u) step(u);
+      }
+      ev = ev_n; dv = dv_n;
     }
   }
   __threadfence_block();
   __syncthreads();
-  // twist index: gamma_i = D+_i + D-_i - (d_i - lambda), smallest |gamma| (both waves scan: no recurrence, pure streaming)
+  // twist index: gamma_i = D+_i + D-_i - (d_i - lambda), smallest |gamma| (both waves scan: no recurrence, pure streaming;
+  // rows past the end repeat row n - 1, which cannot displace the first occurrence of the minimum)
   int r = 0;
   {
     double gbest = 1.7e308;
     for (int i0 = 0; i0 < n; i0 += B) {
       double yp[B], wm[B];
+      const double dv = d[i0 + lane < n ? i0 + lane : n - 1];
 #pragma unroll
       for (int u = 0; u < B; ++u) {
         const int i = i0 + u < n ? i0 + u : n - 1;
@@ -78,30 +119,33 @@ __global__ __launch_bounds__(128) void trd_twisted_kernel(const double* __restri
       }
 #pragma unroll
       for (int u = 0; u < B; ++u) {
-        const int i = i0 + u;
-        if (i < n) {
-          const double g = fabs(yp[u] + wm[u] - (d[i] - l));
-          if (g < gbest) { gbest = g; r = i; }
-        }
+        const int i = i0 + u < n ? i0 + u : n - 1;
+        const double g = fabs(yp[u] + wm[u] - (trd_lane_value(dv, u) - l));
+        if (g < gbest) { gbest = g; r = i; }
       }
     }
   }
   __syncthreads();                                           // (both waves have read D+ before the upper half overwrites it)
   double nrm = 0.0;
   if (half == 0) {
-    // upwards from the twist: z(i) = -(e_i / D+_i) z(i+1)
+    // upwards from the twist: z(i) = -(e_i / D+_i) z(i+1).  The twist index differs from lane to lane: e[i] is a per-lane
+    // load here, requested with the batch of D+
     double z = 1.0;
     nrm = 1.0;
     if (live) Yt[(int64_t)r * ldy + k] = 1.0;
     for (int i0 = r - 1; i0 >= 0; i0 -= B) {
-      double yp[B];
+      double yp[B], eb[B];
 #pragma unroll
-      for (int u = 0; u < B; ++u) yp[u] = i0 - u >= 0 ? Yt[(int64_t)(i0 - u) * ldy + kk] : 1.0;
+      for (int u = 0; u < B; ++u) {
+        const int i = i0 - u >= 0 ? i0 - u : 0;
+        yp[u] = i0 - u >= 0 ? Yt[(int64_t)i * ldy + kk] : 1.0;
+        eb[u] = e[i];
+      }
 #pragma unroll
       for (int u = 0; u < B; ++u) {
         const int i = i0 - u;
         if (i >= 0) {
-          z = -(e[i] * trd_rcp(yp[u])) * z;
+          z = -(eb[u] * trd_rcp(yp[u])) * z;
           if (live) Yt[(int64_t)i * ldy + k] = z;
           nrm += z * z;
         }
@@ -111,14 +155,18 @@ __global__ __launch_bounds__(128) void trd_twisted_kernel(const double* __restri
     // downwards: z(i+1) = -(e_i / D-_{i+1}) z(i)
     double z = 1.0;
     for (int i0 = r; i0 < n - 1; i0 += B) {
-      double wm[B];
+      double wm[B], eb[B];
 #pragma unroll
-      for (int u = 0; u < B; ++u) wm[u] = i0 + u < n - 1 ? W[(int64_t)(i0 + u + 1) * ldy + kk] : 1.0;
+      for (int u = 0; u < B; ++u) {
+        const int i = i0 + u < n - 1 ? i0 + u : n - 2;
+        wm[u] = i0 + u < n - 1 ? W[(int64_t)(i + 1) * ldy + kk] : 1.0;
+        eb[u] = e[i];
+      }
 #pragma unroll
       for (int u = 0; u < B; ++u) {
         const int i = i0 + u;
         if (i < n - 1) {
-          z = -(e[i] * trd_rcp(wm[u])) * z;
+          z = -(eb[u] * trd_rcp(wm[u])) * z;
           if (live) Yt[(int64_t)(i + 1) * ldy + k] = z;
           nrm += z * z;
         }
@@ -137,29 +185,6 @@ __global__ __launch_bounds__(128) void trd_twisted_kernel(const double* __restri
 #pragma unroll
     for (int u = 0; u < B; ++u)
       if (live && i0 + u < h1) Yt[(int64_t)(i0 + u) * ldy + k] = y[u] * s;
-  }
-}
-
-// Zext[i][r] = Vs[r][i] (i < mb, r < 64; zero for r >= nb): 64 of the block's reflectors as extra columns of Z, so that ONE
-// product V^H [Z | V] gives both W = V^H Z and the Gram matrix V^H V
-__global__ void trd_vcopy_kernel(const double* __restrict__ Vr, const double* __restrict__ Vi, int64_t ldv, int nb, int mb,
-                                 double* __restrict__ Er, double* __restrict__ Ei, int64_t lde) {
-  __shared__ double tr[64][65], ti[64][65];
-  const int i0 = blockIdx.x * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;     // 256 threads: 4 rows at a time
-  for (int r = ty; r < 64; r += 4) {
-    const int i = i0 + tx;
-    const bool in = r < nb && i < mb;
-    tr[r][tx] = in ? Vr[(int64_t)r * ldv + i] : 0.0;
-    if (Vi) ti[r][tx] = in ? Vi[(int64_t)r * ldv + i] : 0.0;
-  }
-  __syncthreads();
-  for (int ii = ty; ii < 64; ii += 4) {
-    const int i = i0 + ii;
-    if (i < mb) {
-      Er[(int64_t)i * lde + tx] = tr[tx][ii];
-      if (Vi) Ei[(int64_t)i * lde + tx] = ti[tx][ii];
-    }
   }
 }
 
@@ -210,62 +235,49 @@ struct trd_wy_rows {
   }
 };
 
-// X = T W for one block of reflectors without forming T: T^{-1} = M = striu(V^H V) + diag(1 / tau) is explicit, so every
-// column of W is back-substituted through M (one thread per column, M in LDS, the column in registers).
-// Wx: 64 x ldw planes; columns [0, n) hold W and are overwritten by X, columns [scol, scol + 64) hold V^H V.
+// The 64 x 64 diagonal blocks of T = N^{-1} diag(tau), N = I + diag(tau) striu(S), S = V^H V: column c of a block is the back
+// substitution x_R = (delta_Rc - sum_{l > R} S_Rl x_l) tau_R, R = 63 .. 0 (one thread per column, the block of S in LDS,
+// the column in registers; x_R = 0 below the diagonal comes out of the recurrence).  S and T in the band layout of
+// trd_eigenvectors: element (r, q) at [r * ldb + q] with absolute indices.  tau beyond nref counts as 0 (T row = 0).
 template <bool CPLX>
-__global__ __launch_bounds__(128) void trd_wy_solve_kernel(double* __restrict__ Wr, double* __restrict__ Wi, int64_t ldw, int n, int nb,
-                                                           const double* __restrict__ taur, const double* __restrict__ taui, int scol) {
-  // scol: first column of this block's V^H V inside the rows of Wx (n for a block of <= 64 reflectors; the halves of a block
-  // of 128 pass their own diagonal block of the 128 x 128 Gram matrix)
+__global__ __launch_bounds__(64) void trd_wy_tinv_kernel(const double* __restrict__ Sr, const double* __restrict__ Si, double* __restrict__ Tr,
+                                                         double* __restrict__ Ti, int64_t ldb, int nref, const double* __restrict__ taur,
+                                                         const double* __restrict__ taui) {
   __shared__ __attribute__((aligned(16))) double mr[64][64], mi[CPLX ? 64 : 1][64];
-  // (every load of a phase requested before the first use: unconditional loads from clamped addresses, selected afterwards)
+  const int o = blockIdx.x * 64, c = threadIdx.x;
   {
-    constexpr int PER = 64 * 64 / 128;
-    double ga[PER], gb[PER];
+    double ga[64], gb[CPLX ? 64 : 1];
 #pragma unroll
-    for (int q = 0; q < PER; ++q) {
-      const int e = threadIdx.x + 128 * q, r = e >> 6, c = e & 63;
-      const int rr = r < nb ? r : 0, cc = c < nb ? c : 0;
-      ga[q] = Wr[(int64_t)rr * ldw + scol + cc];
-      gb[q] = CPLX ? Wi[(int64_t)rr * ldw + scol + cc] : 0.0;
+    for (int r = 0; r < 64; ++r) {
+      ga[r] = Sr[(int64_t)(o + r) * ldb + o + c];
+      if (CPLX) gb[r] = Si[(int64_t)(o + r) * ldb + o + c];
     }
 #pragma unroll
-    for (int q = 0; q < PER; ++q) {
-      const int e = threadIdx.x + 128 * q, r = e >> 6, c = e & 63;
+    for (int r = 0; r < 64; ++r) {
       double a = 0.0, b = 0.0;
-      if (r < nb && c < nb) {
-        if (c > r) {
-          a = ga[q];
-          b = gb[q];
-        } else if (c == r) {
-          // the diagonal holds 1 / M_rr = tau_r (tau = 0: the stored reflector is the zero vector, any finite value does)
-          a = taur[r];
-          if (CPLX) b = taui[r];
-        }
+      if (c > r) {
+        a = ga[r];
+        if (CPLX) b = gb[r];
+      } else if (c == r && o + r < nref) {
+        a = taur[o + r];
+        if (CPLX) b = taui[o + r];
       }
       mr[r][c] = a;
       if (CPLX) mi[r][c] = b;
     }
   }
   __syncthreads();
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n) return;
   double xr[64], xi[CPLX ? 64 : 1];
 #pragma unroll
   for (int r = 0; r < 64; ++r) {
-    const int rr = r < nb ? r : 0;
-    const double vr = Wr[(int64_t)rr * ldw + k], vi = CPLX ? Wi[(int64_t)rr * ldw + k] : 0.0;
-    xr[r] = r < nb ? vr : 0.0;
-    if (CPLX) xi[r] = r < nb ? vi : 0.0;
+    xr[r] = r == c ? 1.0 : 0.0;
+    if (CPLX) xi[r] = 0.0;
   }
   trd_wy_rows<CPLX, 63>::run(xr, xi, mr, mi);
 #pragma unroll
-  for (int r = 0; r < 64; ++r) {
-    if (r < nb) {
-      Wr[(int64_t)r * ldw + k] = xr[r];
-      if (CPLX) Wi[(int64_t)r * ldw + k] = xi[r];
-    }
+  for (int r = 0; r < 64; ++r) {           // (row r of the block: 64 consecutive doubles across the lanes)
+    Tr[(int64_t)(o + r) * ldb + o + c] = xr[r];
+    if (CPLX) Ti[(int64_t)(o + r) * ldb + o + c] = xi[r];
   }
 }
 
@@ -311,11 +323,65 @@ __global__ void trd_ns_matrix_kernel(const double* __restrict__ Sr, const double
   }
 }
 
+// Tile lists of the compact-WY precomputation for one matrix order (kept in the workspace: the order rarely changes)
+constexpr int TRD_SBK = 512;                 // reflectors per super-block of the back-transformation (4 block tiles)
+struct TrdBackPlan {
+  int n = 0;
+  GemmTileList gram;                         // S = conj(V) V^T inside the diagonal super-blocks, upper block triangle
+  GemmTileList lev_p[3], lev_t[3];           // levels h = 64, 128, 256:  P = S12 T22,  T12 = -T11 P
+  GemmTileList tv;                           // T conj(V)
+  void build(hipStream_t st, int n_) {
+    n = n_;
+    constexpr int Q = TRD_SBK / 128;
+    const int nt = ceil_div(n, 128), nsb = ceil_div(n, TRD_SBK);
+    std::vector<int> t, k;
+    auto add = [&](int bm, int bn, int k0, int k1) { t.push_back((bm << 16) | bn); k.push_back(k0); k.push_back(k1); };
+    auto done = [&](GemmTileList& l) { l.upload(st, t, k); t.clear(); k.clear(); };
+    // reflector r is zero up to column r: the contraction starts at the block row's first column
+    for (int s = 0; s < nsb; ++s)
+      for (int bm = Q * s; bm < std::min(Q * s + Q, nt); ++bm)
+        for (int bn = bm; bn < std::min(Q * s + Q, nt); ++bn) add(bm, bn, 128 * bm, n);
+    done(gram);
+    // h = 64: both halves of a pair inside one block tile
+    for (int b = 0; b < nt; ++b) add(b, b, 128 * b + 64, 128 * b + 128);
+    done(lev_p[0]);
+    for (int b = 0; b < nt; ++b) add(b, b, 128 * b, 128 * b + 64);
+    done(lev_t[0]);
+    // h = 128: block tiles (2 z, 2 z + 1) of a super-block
+    for (int lv = 0; lv < 2; ++lv) {
+      for (int s = 0; s < nsb; ++s)
+        for (int z = 0; z < Q / 2; ++z) {
+          const int a = Q * s + 2 * z;
+          if (a + 1 < nt) add(a, a + 1, 128 * (a + (lv == 0 ? 1 : 0)), 128 * (a + (lv == 0 ? 2 : 1)));
+        }
+      done(lv == 0 ? lev_p[1] : lev_t[1]);
+    }
+    // h = 256: block tiles (a, b), a in the first half of the super-block, b in the second
+    for (int lv = 0; lv < 2; ++lv) {
+      for (int s = 0; s < nsb; ++s)
+        for (int a = Q * s; a < Q * s + Q / 2; ++a)
+          for (int b = Q * s + Q / 2; b < std::min(Q * s + Q, nt); ++b)
+            add(a, b, 128 * (Q * s + (lv == 0 ? Q / 2 : 0)), 128 * (Q * s + (lv == 0 ? Q : Q / 2)));
+      done(lv == 0 ? lev_p[2] : lev_t[2]);
+    }
+    // T conj(V): row block bm of T is zero left of its diagonal tile and right of its super-block; V is zero left of the
+    // super-block's first column in these rows
+    for (int bm = 0; bm < nt; ++bm) {
+      const int s = bm / Q;
+      for (int bn = Q * s; bn < nt; ++bn) add(bm, bn, 128 * bm, std::min(128 * (Q * s + Q), n));
+    }
+    done(tv);
+  }
+};
+
 struct TrdVecWorkspace {
   DevBuf<double> Y[2];        // Yt / Z (n x ld planes)
   DevBuf<double> Wk[2];       // work planes (twisted factorisation; Newton-Schulz)
   DevBuf<double> S[2];        // Gram matrix of the vectors
-  DevBuf<double> small;       // S_b, T_b (64 x 64 planes), W_b, X_b (64 x ld planes)
+  DevBuf<double> small;       // X of one super-block (512 x ld planes)
+  DevBuf<double> band[2];     // S, T, P of the compact-WY precomputation (band layout), re / im
+  DevBuf<double> TV[2];       // T V^H (n x ldv planes)
+  TrdBackPlan plan;
   DevBuf<double> lam_asc;
   DevBuf<unsigned long long> orth;
   double last_orth = 0.0;     // max |Z^H Z - I| before the clean-up of the last call
@@ -328,11 +394,9 @@ struct TrdVecWorkspace {
 inline bool trd_eigenvectors(hipStream_t st, TrdWorkspace& ws, TrdVecWorkspace& vw, GemmWorkspace& gws, const TrdParams& P, bool cplx,
                              double* Zr, double* Zi, int64_t ldz) {
   const int n = P.n;
-  const int64_t ldv = P.ld;                                   // reflectors
-  // reflectors per block of the back-transformation: 128 (two skinny GEMMs per block at twice the depth, half the passes over
-  // Z; the 128 x 128 system T^{-1} X = W is solved in two halves of 64 with one small product in between) or 64
-  constexpr int NBK = 128;       // (blocks of 64 - round 3's first form - took 8.1 instead of 6.5 ms at n = 2920)
-  const int64_t ld = ((int64_t)n + NBK + 15) & ~(int64_t)15;   // Z with NBK extra columns (the block's reflectors, see trd_vcopy_kernel)
+  const int64_t ldv = P.ld;                                   // reflectors: row j = v_j, zero outside its support j+1 .. n-1
+  constexpr int SBK = TRD_SBK;
+  const int64_t ld = ((int64_t)n + 15) & ~(int64_t)15;
   const size_t plane = (size_t)n * ld;
   double* Yr = vw.Y[0].ensure(plane);
   double* Yi = cplx ? vw.Y[1].ensure(plane) : nullptr;
@@ -341,43 +405,54 @@ inline bool trd_eigenvectors(hipStream_t st, TrdWorkspace& ws, TrdVecWorkspace& 
   hipLaunchKernelGGL(trd_twisted_kernel, dim3(ceil_div(n, 64)), dim3(128), 0, st, P.d, P.e, n, vw.lam_asc.get(), Wr, Yr, ld);
   XMCA_HIP(hipGetLastError());
   if (cplx) XMCA_HIP(hipMemsetAsync(Yi, 0, sizeof(double) * plane, st));
-  // ---- Z = H_0 H_1 ... H_{n-2} Yt, blocks of 64 reflectors from the last to the first:  Z -= V (T (V^H Z)) ----
-  double* sm = vw.small.ensure(2 * (size_t)NBK * ld);
-  double* Wbr = sm; double* Wbi = Wbr + (size_t)NBK * ld;
   const int nref = n - 1;
-  auto solve = [&](int row0, int rows, int scol, int jtau) {   // X = T W for the rows [row0, row0 + rows) of the block, in place
-    double* wr = Wbr + (int64_t)row0 * ld;
-    double* wi = cplx ? Wbi + (int64_t)row0 * ld : nullptr;
-    if (cplx) hipLaunchKernelGGL(trd_wy_solve_kernel<true>, dim3(ceil_div(n, 128)), dim3(128), 0, st, wr, wi, ld, n, rows, P.tau[0] + jtau, P.tau[1] + jtau, scol);
-    else hipLaunchKernelGGL(trd_wy_solve_kernel<false>, dim3(ceil_div(n, 128)), dim3(128), 0, st, wr, nullptr, ld, n, rows, P.tau[0] + jtau, nullptr, scol);
-  };
-  for (int j0 = ((nref - 1) / NBK) * NBK; j0 >= 0; j0 -= NBK) {
-    const int nb = std::min(NBK, nref - j0);
-    const int i0 = j0 + 1, mb = n - i0;                      // support of the block: rows i0 .. n-1
-    const double* Vbr = P.Vr + (int64_t)j0 * ldv + i0;       // Vs[r][i - i0], r < nb  (row-major, k fast)
-    const double* Vbi = cplx ? P.Vi + (int64_t)j0 * ldv + i0 : nullptr;
-    double* Zr0 = Yr + (int64_t)i0 * ld;
-    double* Zi0 = cplx ? Yi + (int64_t)i0 * ld : nullptr;
-    for (int h = 0; h < NBK; h += 64)                         // (zero columns for the reflectors a short last block does not have)
-      hipLaunchKernelGGL(trd_vcopy_kernel, dim3(ceil_div(mb, 64)), dim3(256), 0, st, Vbr + (int64_t)h * ldv, cplx ? Vbi + (int64_t)h * ldv : nullptr,
-                         ldv, std::max(0, std::min(64, nb - h)), mb, Zr0 + n + h, cplx ? Zi0 + n + h : nullptr, ld);
-    // [W | S] = V^H [Z | V]  (nb x (n + NBK)):  W[r][k] = sum_i conj(Vs[r][i]) Z[i][k]
-    cgemm<double>(st, gws, Vbr, Vbi, ldv, true, true, Zr0, Zi0, ld, true, false, Wbr, cplx ? Wbi : nullptr, ld, nb, n + NBK, mb, 1.0, nullptr,
-                  nullptr, false);
-    // X = T W, in place:  T^{-1} = M = striu(S) + diag(1 / tau) is upper triangular - the rows from 64 on first, then they are
-    // taken out of the first 64 rows (W_1 -= M_12 X_2), then those
-    if (nb > 64) {
-      const int h2 = nb - 64;
-      solve(64, h2, n + 64, j0 + 64);
-      cgemm<double>(st, gws, Wbr + n + 64, cplx ? Wbi + n + 64 : nullptr, ld, true, false, Wbr + (int64_t)64 * ld, cplx ? Wbi + (int64_t)64 * ld : nullptr, ld,
-                    true, false, Wbr, cplx ? Wbi : nullptr, ld, 64, n, h2, -1.0, nullptr, nullptr, false, 1.0);
-      solve(0, 64, n, j0);
-    } else {
-      solve(0, nb, n, j0);
+  if (nref > 0) {
+    // ---- T of every super-block and T V^H, from the reflectors alone ----
+    // Band layout: element (r, q) of S / T / P at [r * SBK + q] with ABSOLUTE indices - only entries of one diagonal
+    // super-block are ever touched, so super-block s sits at s * (SBK * SBK + SBK) and the three matrices are ordinary GEMM
+    // operands with leading dimension SBK; rows and columns past n stay zero.
+    if (vw.plan.n != n) vw.plan.build(st, n);
+    const TrdBackPlan& pl = vw.plan;
+    const int nsb = ceil_div(n, SBK), npad = nsb * SBK;
+    const size_t bsz = (size_t)nsb * ((size_t)SBK * SBK + SBK) + SBK;
+    double* bnd[2] = {vw.band[0].ensure(3 * bsz), cplx ? vw.band[1].ensure(3 * bsz) : nullptr};
+    for (int c = 0; c < (cplx ? 2 : 1); ++c) XMCA_HIP(hipMemsetAsync(bnd[c], 0, sizeof(double) * 3 * bsz, st));
+    double *Sr_ = bnd[0], *Tr_ = bnd[0] + bsz, *Pr_ = bnd[0] + 2 * bsz;
+    double *Si_ = cplx ? bnd[1] : nullptr, *Ti_ = cplx ? bnd[1] + bsz : nullptr, *Pi_ = cplx ? bnd[1] + 2 * bsz : nullptr;
+    // S[r][q] = sum_i conj(V[r][i]) V[q][i]
+    cgemm<double>(st, gws, P.Vr, P.Vi, ldv, true, true, P.Vr, P.Vi, ldv, false, false, Sr_, Si_, SBK, n, n, n, 1.0, nullptr, nullptr, false,
+                  0.0, &pl.gram);
+    if (cplx) hipLaunchKernelGGL(trd_wy_tinv_kernel<true>, dim3(ceil_div(n, 64)), dim3(64), 0, st, Sr_, Si_, Tr_, Ti_, (int64_t)SBK, nref, P.tau[0], P.tau[1]);
+    else hipLaunchKernelGGL(trd_wy_tinv_kernel<false>, dim3(ceil_div(n, 64)), dim3(64), 0, st, Sr_, nullptr, Tr_, nullptr, (int64_t)SBK, nref, P.tau[0], nullptr);
+    for (int lv = 0; lv < 3; ++lv) {
+      // P = S12 T22 (contraction over the second half of the pair), T12 = -T11 P (over the first half).  Rows of a block
+      // tile outside the wanted half see exact zeros of T (upper triangular, block diagonal so far) on one side of every
+      // product, so whole tiles can be computed and stored.
+      cgemm<double>(st, gws, Sr_, Si_, SBK, true, false, Tr_, Ti_, SBK, true, false, Pr_, Pi_, SBK, npad, npad, npad, 1.0, nullptr, nullptr,
+                    false, 0.0, &pl.lev_p[lv]);
+      cgemm<double>(st, gws, Tr_, Ti_, SBK, true, false, Pr_, Pi_, SBK, true, false, Tr_, Ti_, SBK, npad, npad, npad, -1.0, nullptr, nullptr,
+                    false, 1.0, &pl.lev_t[lv]);
     }
-    // Z[i0:, :] -= V X      (A(m = i, k = r) = Vs[r][i]: the k-slow orientation)
-    cgemm<double>(st, gws, Vbr, Vbi, ldv, false, false, Wbr, cplx ? Wbi : nullptr, ld, true, false, Zr0, Zi0, ld, mb, n, nb, -1.0, nullptr,
-                  nullptr, false, 1.0);
+    // TV[r][i] = sum_q T[r][q] conj(V[q][i])
+    double* TVr = vw.TV[0].ensure((size_t)n * ldv);
+    double* TVi = cplx ? vw.TV[1].ensure((size_t)n * ldv) : nullptr;
+    cgemm<double>(st, gws, Tr_, Ti_, SBK, true, false, P.Vr, P.Vi, ldv, true, true, TVr, TVi, ldv, n, n, n, 1.0, nullptr, nullptr, false, 0.0,
+                  &pl.tv);
+    // ---- Z = H_0 H_1 ... H_{n-2} Yt, super-blocks from the last to the first:  X = (T V^H) Z,  Z -= V X ----
+    double* sm = vw.small.ensure(2 * (size_t)SBK * ld);
+    double* Xr = sm; double* Xi = cplx ? Xr + (size_t)SBK * ld : nullptr;
+    for (int j0 = ((nref - 1) / SBK) * SBK; j0 >= 0; j0 -= SBK) {
+      const int nb = std::min(SBK, nref - j0);
+      const int i0 = j0 + 1, mb = n - i0;                    // support of the super-block: rows i0 .. n-1
+      const int64_t vo = (int64_t)j0 * ldv + i0;             // Vs[r][i - i0], r < nb  (row-major, contraction index fast)
+      double* Zr0 = Yr + (int64_t)i0 * ld;
+      double* Zi0 = cplx ? Yi + (int64_t)i0 * ld : nullptr;
+      cgemm<double>(st, gws, TVr + vo, cplx ? TVi + vo : nullptr, ldv, true, false, Zr0, Zi0, ld, true, false, Xr, Xi, ld, nb, n, mb, 1.0, nullptr,
+                    nullptr, false);
+      // Z[i0:, :] -= V X      (A(m = i, k = r) = Vs[r][i]: the k-slow orientation)
+      cgemm<double>(st, gws, P.Vr + vo, cplx ? P.Vi + vo : nullptr, ldv, false, false, Xr, Xi, ld, true, false, Zr0, Zi0, ld, mb, n, nb, -1.0,
+                    nullptr, nullptr, false, 1.0);
+    }
   }
   XMCA_HIP(hipGetLastError());
   // ---- orthonormality of the result, Newton-Schulz clean-up, transposition into the caller's layout ----
