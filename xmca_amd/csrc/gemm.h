@@ -2,7 +2,8 @@
 //
 // * f64 operands -> v_mfma_f64_16x16x4_f64, f32 operands -> v_mfma_f32_16x16x4_f32 (exact f32) with three levels of
 //   accumulation ("WIDE", see GEMM_FLUSH_PRODUCTS) - or, for float32 products with both operands contiguous along the
-//   contraction, six v_mfma_f32_32x32x16_bf16 on three-way bfloat16 pieces of the operands ("X3").
+//   contraction - or A so and B row-fast, the back-projection - six v_mfma_f32_32x32x16_bf16 on three-way bfloat16 pieces of
+//   the operands ("X3").
 // * 128 x 128 block tile, 256 threads = 4 waves (2 x 2), each wave a 64 x 64 tile = 4 x 4 MFMA tiles; two workgroups per CU
 //   (one wave of each on every SIMD, 256 registers per lane each: accumulators + second-level sums + two sets of fragments
 //   fit, no scratch in any instantiation).
@@ -195,7 +196,8 @@ static __device__ __forceinline__ int gemm_lane_id() {
   return l;
 }
 
-// X3 (float operands, both contiguous along the contraction: the covariance / Gram product of a float32 field): every float32
+// X3 (float operands, A contiguous along the contraction: the covariance / Gram product of a float32 field and its
+// back-projection): every float32
 // element is split into three bfloat16 pieces on the way from LDS to the matrix pipe - x = h + m + l, 8 mantissa bits each,
 // see gemm_split3 - and the product runs as six
 // v_mfma_f32_32x32x16_bf16 per tile and 16 contraction indices, a.b ~ hh + (hm + mh) + (mm + hl + lh); the three terms left
@@ -228,7 +230,7 @@ static __device__ __forceinline__ void gemm_split3(const f4_t& x0, const f4_t& x
 
 template <typename TI, typename TO, bool A_KFAST, bool B_NFAST, bool WIDE, bool X3 = false>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams<TI, TO> p) {
-  static_assert(!X3 || (std::is_same<TI, float>::value && A_KFAST && !B_NFAST && WIDE), "X3: float32, both operands K-fast");
+  static_assert(!X3 || (std::is_same<TI, float>::value && A_KFAST && WIDE), "X3: float32, A contiguous along the contraction");
   using M_ = Mfma<TI>;
   using acc_t = typename M_::acc_t;
   using vec_t = typename M_::vec_t;
@@ -349,7 +351,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams<TI, TO
   // X3 fragments: lane (i = lane & 31, kk = lane >> 5) reads the 8 floats k = 16 q + 8 kk ... + 7 of row w0 + 32 t + i - two
   // neighbouring 16-byte chunks (c, c ^ 1 after the swizzle), conflict-free like the reads of the float32 path
   int fa0 = X3 ? (wm + (lane & 31)) * 128 + (((2 * (lane >> 5)) ^ (((lane & 31) >> 1) & 7)) << 4) : OA::frag_base(wm, lane);
-  int fb0 = (X3 ? (wn + (lane & 31)) * 128 + (((2 * (lane >> 5)) ^ (((lane & 31) >> 1) & 7)) << 4) : OB::frag_base(wn, lane)) + SB;
+  // (X3, B row-fast - the back-projection of a float32 field: the lane's 8 values are one float from each of the k-rows
+  //  16 q + 8 kk + j at column w0 + 32 t + i: ds_read_b32 over 32 consecutive floats per lane group, conflict-free; row pairs
+  //  (j, j + 1) share the row swizzle and sit 512 bytes apart - one ds_read2_b32)
+  int fb0 = (X3 ? (B_NFAST ? (lane >> 5) * 4096 + (wn + (lane & 31)) * 4
+                           : (wn + (lane & 31)) * 128 + (((2 * (lane >> 5)) ^ (((lane & 31) >> 1) & 7)) << 4))
+                : OB::frag_base(wn, lane)) + SB;
   constexpr int NFR = X3 ? 1 : 4, NQ = X3 ? 2 : NPH;        // (X3: one phase = 16 contraction indices)
   frag_t af[X3 ? 1 : 2][NFR], bf[X3 ? 1 : 2][NFR];
   f4_t ar3[X3 ? 2 : 1][2], br3[X3 ? 2 : 1][2];              // X3: raw floats of the NEXT phase
@@ -357,11 +364,18 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams<TI, TO
     asm("" : "+v"(fa0), "+v"(fb0));
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const int oa = (fa0 ^ (q << 6)) + t * 4096, ob = (fb0 ^ (q << 6)) + t * 4096;
+      const int oa = (fa0 ^ (q << 6)) + t * 4096;
       ar3[t][0] = *reinterpret_cast<const f4_t*>(sb + oa);
       ar3[t][1] = *reinterpret_cast<const f4_t*>(sb + (oa ^ 16));
-      br3[t][0] = *reinterpret_cast<const f4_t*>(sb + ob);
-      br3[t][1] = *reinterpret_cast<const f4_t*>(sb + (ob ^ 16));
+      if constexpr (!B_NFAST) {
+        const int ob = (fb0 ^ (q << 6)) + t * 4096;
+        br3[t][0] = *reinterpret_cast<const f4_t*>(sb + ob);
+        br3[t][1] = *reinterpret_cast<const f4_t*>(sb + (ob ^ 16));
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          br3[t][j >> 2][j & 3] = *reinterpret_cast<const float*>(sb + fb0 + (16 * q + j) * 512 + ((t ^ ((j >> 1) & 1)) << 7));
+      }
     }
   };
   u4_t ah[X3 ? 2 : 1], am[X3 ? 2 : 1], al[X3 ? 2 : 1], bh[X3 ? 2 : 1], bm3[X3 ? 2 : 1], bl[X3 ? 2 : 1];
@@ -680,8 +694,8 @@ struct GemmWorkspace {
   }
 };
 
-// float32 products with both operands contiguous along the contraction (Gram / covariance of a float32 field) by three-way
-// bfloat16 splitting (X3 in the kernel): on unless XMCA_GEMM_BF16X3=0
+// float32 products whose A operand is contiguous along the contraction (Gram / covariance of a float32 field, its
+// back-projection) by three-way bfloat16 splitting (X3 in the kernel): on unless XMCA_GEMM_BF16X3=0
 static inline bool gemm_x3_enabled() {
   static const bool on = [] { const char* e = std::getenv("XMCA_GEMM_BF16X3"); return !(e && e[0] == '0'); }();
   return on;
@@ -691,8 +705,9 @@ template <typename TI, typename TO, bool WIDE>
 static void launch_gemm_variant(hipStream_t st, const GemmParams<TI, TO>& p, bool a_kfast, bool b_nfast) {
   dim3 grid(p.n_wg), block(GEMM_THREADS);
   if constexpr (std::is_same<TI, float>::value) {
-    if (a_kfast && !b_nfast && gemm_x3_enabled()) {
-      hipLaunchKernelGGL((gemm_kernel<TI, TO, true, false, WIDE, true>), grid, block, 0, st, p);
+    if (a_kfast && gemm_x3_enabled()) {
+      if (b_nfast) hipLaunchKernelGGL((gemm_kernel<TI, TO, true, true, WIDE, true>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((gemm_kernel<TI, TO, true, false, WIDE, true>), grid, block, 0, st, p);
       XMCA_HIP(hipGetLastError());
       return;
     }
