@@ -648,6 +648,30 @@ def test_float32_model_keeps_float32_vectors_and_rotates_them_on_the_device():
     assert np.max(np.abs(Va - om.V[0][:, :5])) < 1e-3
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_few_modes_on_a_long_grid_have_unit_norm(dtype):
+    """T = 10 samples on 70 000 grid points: the null mode of the centered field (and every mode under the dtype's cut) is
+    normalised by its measured norm, with one workgroup per CHUNK of a row when the rows are few and long (csrc/kernels.h
+    normalize_rows; one workgroup per row took 2.5 ms on C5's 10^6-point rows).  All modes: unit norm; the non-null ones
+    agree with the oracle (array.py:580-584)."""
+    rng = np.random.default_rng(31)
+    T, N = 10, 70000
+    X = (rng.standard_normal((T, 3)) @ rng.standard_normal((3, N)) * 4 + rng.standard_normal((T, N))).astype(dtype)
+    m = MCA(X)
+    m.solve()
+    V = np.asarray(m._V['left'])
+    assert V.shape == (N, T) and V.dtype == dtype
+    nrm = np.linalg.norm(V.astype(np.float64), axis=0)
+    # (float32: the modes above the cut are scaled by 1 / sqrt(lambda), lambda from float32 products: ~1e-7 lambda_0 / lambda)
+    assert np.max(np.abs(nrm - 1.0)) < (1e-5 if dtype == np.float32 else 1e-12), nrm
+    assert abs(nrm[-1] - 1.0) < (2e-7 if dtype == np.float32 else 1e-12)             # the null mode: measured norm
+    om = O.OracleModel(X)
+    om.solve()
+    k = T - 1
+    Va, _ = align_modes(V[:, :k].astype(np.float64), om.V[0][:, :k].astype(np.float64))
+    assert np.max(np.abs(Va - om.V[0][:, :k])) < (1e-3 if dtype == np.float32 else 1e-9)
+
+
 def test_unconverged_eigensolver_raises_like_gesdd(monkeypatch):
     """the Jacobi sweeps either reach their stopping rule or the solve raises LinAlgError (numpy's 'SVD did not
     converge'): an unconverged basis is never returned as singular vectors."""

@@ -241,6 +241,59 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(T* __restrict__ re,
   if (norms_out && threadIdx.x == 0) norms_out[r] = nrm;
 }
 
+// The same for a few LONG rows (the null mode of a centered float32 field with 10^6 grid points: one workgroup walking a
+// whole row takes 2.5 ms): a row is cut into chunks of ROWN_CHUNK columns, partial sums of squares per (row, chunk), then
+// every chunk scales itself by the sum of its row's partials taken in chunk order (deterministic, no atomics).
+constexpr int ROWN_CHUNK = 8192;
+template <typename T>
+__global__ __launch_bounds__(256) void row_sumsq_chunk_kernel(const T* __restrict__ re, const T* __restrict__ im, int64_t ld, int cols,
+                                                              double* __restrict__ part) {
+  __shared__ double red[4];
+  const int64_t r = blockIdx.y;
+  const int c0 = blockIdx.x * ROWN_CHUNK, c1 = min(cols, c0 + ROWN_CHUNK);
+  double acc = 0.0;
+  for (int c = c0 + threadIdx.x; c < c1; c += 256) {
+    const double a = (double)re[r * ld + c];
+    acc += a * a;
+    if (im) {
+      const double b = (double)im[r * ld + c];
+      acc += b * b;
+    }
+  }
+  const double s = block_sum_256(acc, red);
+  if (threadIdx.x == 0) part[r * gridDim.x + blockIdx.x] = s;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void row_scale_chunk_kernel(T* __restrict__ re, T* __restrict__ im, int64_t ld, int cols, int conj,
+                                                              const double* __restrict__ part, double* __restrict__ norms_out) {
+  const int64_t r = blockIdx.y;
+  double tot = 0.0;
+  for (int q = 0; q < (int)gridDim.x; ++q) tot += part[r * gridDim.x + q];
+  const double nrm = sqrt(tot);
+  const double inv = nrm > 0.0 ? 1.0 / nrm : 0.0;
+  const int c0 = blockIdx.x * ROWN_CHUNK, c1 = min(cols, c0 + ROWN_CHUNK);
+  for (int c = c0 + threadIdx.x; c < c1; c += 256) {
+    re[r * ld + c] = (T)((double)re[r * ld + c] * inv);
+    if (im) im[r * ld + c] = (T)((double)im[r * ld + c] * (conj ? -inv : inv));
+  }
+  if (norms_out && blockIdx.x == 0 && threadIdx.x == 0) norms_out[r] = nrm;
+}
+// rows <- conj?(rows) / ||row||: one workgroup per row, or - few long rows - one per chunk of a row
+template <typename T>
+static inline void normalize_rows(hipStream_t st, T* re, T* im, int64_t ld, int rows, int cols, int conj, double* norms_out) {
+  if (rows <= 0) return;
+  const int chunks = ceil_div(cols, ROWN_CHUNK);
+  if (rows >= 256 || chunks < 4) {
+    hipLaunchKernelGGL((normalize_rows_kernel<T>), dim3(rows), dim3(256), 0, st, re, im, ld, cols, conj, norms_out);
+  } else {
+    DevBuf<double> part;       // (returned to the stream's pool: the kernels queued here are ahead of its next user)
+    part.ensure((size_t)rows * chunks);
+    hipLaunchKernelGGL((row_sumsq_chunk_kernel<T>), dim3(chunks, rows), dim3(256), 0, st, (const T*)re, (const T*)im, ld, cols, part.get());
+    hipLaunchKernelGGL((row_scale_chunk_kernel<T>), dim3(chunks, rows), dim3(256), 0, st, re, im, ld, cols, conj, (const double*)part.get(), norms_out);
+  }
+  XMCA_HIP(hipGetLastError());
+}
+
 // Column passes of the constructor stage.  A thread per column alone leaves the chip empty (10^4 columns = 40 workgroups):
 // the rows are split into gridDim.y chunks, every (chunk, column) writes its partial result to part[chunk][c], and a
 // finishing kernel adds the chunks in a fixed order (no floating-point atomics: results do not depend on scheduling).

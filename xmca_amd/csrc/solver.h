@@ -204,8 +204,7 @@ class Solver {
         }
         gemm<float, float>(st, gws, y.r, T, f.r(), f.N, V, f.N, m, (int)f.N, T, o);
         if (n_known < m)
-          hipLaunchKernelGGL((normalize_rows_kernel<float>), dim3(m - n_known), dim3(256), 0, st, V + (int64_t)n_known * f.N, (float*)nullptr,
-                             f.N, (int)f.N, 0, (double*)nullptr);
+          normalize_rows<float>(st, V + (int64_t)n_known * f.N, nullptr, f.N, m - n_known, (int)f.N, 0, nullptr);
         XMCA_HIP(hipGetLastError());
         XMCA_HIP(hipStreamSynchronize(st));
         return;
@@ -220,13 +219,12 @@ class Solver {
       cgemm<TI>(st, gws, y.r, y.i, T, true, true, f.r(), f.i(), f.N, true, true, Vt.r(), Vt.i(cplx), f.N, m, (int)f.N, T, 1.0,
                 inv_dev.get(), nullptr, false);
       if (n_known < m)
-        hipLaunchKernelGGL((normalize_rows_kernel<double>), dim3(m - n_known), dim3(256), 0, st, Vt.r() + (int64_t)n_known * f.N,
-                           cplx ? Vt.i(cplx) + (int64_t)n_known * f.N : nullptr, f.N, (int)f.N, 0, (double*)nullptr);
+        normalize_rows<double>(st, Vt.r() + (int64_t)n_known * f.N, cplx ? Vt.i(cplx) + (int64_t)n_known * f.N : nullptr, f.N, m - n_known,
+                               (int)f.N, 0, nullptr);
     } else {
       cgemm<TI>(st, gws, y.r, y.i, T, true, false, f.r(), f.i(), f.N, true, false, Vt.r(), Vt.i(cplx), f.N, m, (int)f.N, T, 1.0,
                 nullptr, nullptr, false);
-      hipLaunchKernelGGL((normalize_rows_kernel<double>), dim3(m), dim3(256), 0, st, Vt.r(), Vt.i(cplx), f.N, (int)f.N, 1,
-                         (double*)nullptr);
+      normalize_rows<double>(st, Vt.r(), Vt.i(cplx), f.N, m, (int)f.N, 1, nullptr);
     }
     XMCA_HIP(hipGetLastError());
     XMCA_HIP(hipStreamSynchronize(st));   // `y` temporaries are released on return
@@ -833,9 +831,7 @@ class Solver {
     // Vt = Bt X  (complex x real field)
     cgemm<TI>(st, gws, bt.r, bt.i, T, true, false, f.r(), nullptr, f.N, true, false, Vt.r(), Vt.im.get(), f.N, nv, (int)f.N, T, 1.0,
               nullptr, nullptr, false);
-    hipLaunchKernelGGL((normalize_rows_kernel<double>), dim3(nv), dim3(256), 0, st, Vt.r(), Vt.im.get(), f.N, (int)f.N, 0,
-                       (double*)nullptr);
-    XMCA_HIP(hipGetLastError());
+    normalize_rows<double>(st, Vt.r(), Vt.im.get(), f.N, nv, (int)f.N, 0, nullptr);
     XMCA_HIP(hipStreamSynchronize(st));
   }
 
