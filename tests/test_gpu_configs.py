@@ -140,6 +140,7 @@ def _check_config(gold, name, cplx, n_rot, power, preprocess):
     fields = make_input(name)
     f32 = fields[0].dtype == np.float32
     m = MCA(*fields, preprocess=preprocess)
+    m._device().reset_timings()          # (the default handle is shared by the process: stage names of earlier tests would linger)
     m.solve(complexify=cplx)
     gs = g["singular_values"]
     s = m._singular_values.astype(np.float64)

@@ -815,6 +815,164 @@ __device__ __forceinline__ int varimax_ns_wave16(const double* __restrict__ Gr, 
   return it < 100 ? it : -1;
 }
 
+// ---- the whole polar step for p <= 16 in ONE wave (round 4) ----
+// DPP move of a double (both halves) and sums / minima over the 16 lanes of a DPP row and over the wave.
+template <int CTRL>
+__device__ __forceinline__ double rot_dpp(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror: every lane of a row ends up with the row's total
+__device__ __forceinline__ double rot_row_sum(double v) {
+  v += rot_dpp<0xB1>(v);
+  v += rot_dpp<0x4E>(v);
+  v += rot_dpp<0x141>(v);
+  v += rot_dpp<0x140>(v);
+  return v;
+}
+__device__ __forceinline__ double rot_row_min(double v) {
+  v = fmin(v, rot_dpp<0xB1>(v));
+  v = fmin(v, rot_dpp<0x4E>(v));
+  v = fmin(v, rot_dpp<0x141>(v));
+  v = fmin(v, rot_dpp<0x140>(v));
+  return v;
+}
+__device__ __forceinline__ double rot_lane(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ double rot_wave_sum(double v) {      // (rows added in a fixed order; uniform)
+  v = rot_row_sum(v);
+  return ((rot_lane(v, 0) + rot_lane(v, 16)) + rot_lane(v, 32)) + rot_lane(v, 48);
+}
+
+// G (p x p, LDS) -> R = polar factor, c, d and the stopping rule: what varimax_polar_step does behind the sum of the partials,
+// by one wave without a barrier or an LDS round trip.  Everything lives in the C/D layout of varimax_ns_wave16 (lane l,
+// register r <-> entry [l / 16 + 4 r][l % 16]): ||G||_F, d = Re tr(R^H G), H_kk and the column sums c_k = Re sum_j conj(R_jk)
+// (A0 R)_jk are in-lane sums over r, two cross-row exchanges and DPP row reductions; A0 R = S(A0^T, R) is four (real) MFMAs on
+// the registers the iteration leaves behind.  The block-wide form took 5k cycles for this tail and two barriers for the norm.
+template <bool CPLX>
+__device__ __forceinline__ void varimax_polar_wave16_full(const double* __restrict__ Gr, const double* __restrict__ Gi, const int p,
+                                                          const double* __restrict__ A0r, const double* __restrict__ A0i,
+                                                          double* __restrict__ Rr, double* __restrict__ Ri, double* __restrict__ cvec,
+                                                          double* __restrict__ state, const double tol) {
+  const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+  double g_r[4], g_i[4], xr[4], xtr[4], xi[4], xti[4];
+  bool in[4];
+  double f2 = 0.0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = l4 + 4 * r, col = l15;
+    in[r] = row < p && col < p;
+    g_r[r] = in[r] ? Gr[row * p + col] : 0.0;
+    xtr[r] = in[r] ? Gr[col * p + row] : 0.0;
+    g_i[r] = (CPLX && in[r]) ? Gi[row * p + col] : 0.0;
+    xti[r] = (CPLX && in[r]) ? Gi[col * p + row] : 0.0;
+    f2 += g_r[r] * g_r[r] + g_i[r] * g_i[r];
+  }
+  const double inv = 1.0 / sqrt(rot_wave_sum(f2));
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    xr[r] = g_r[r] * inv;
+    xtr[r] *= inv;
+    xi[r] = g_i[r] * inv;
+    xti[r] *= inv;
+  }
+  auto S = [](const double (&P)[4], const double (&Q)[4], d4_t acc, const double sign) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc = Mfma<double>::mma(sign * P[r], Q[r], acc);
+    return acc;
+  };
+  const d4_t zero = {0, 0, 0, 0};
+  double ell = (state[6] > 1e-6 && state[6] < 1.0) ? state[6] : 1e-3;
+  int it = 0;
+  for (; it < 100; ++it) {
+    d4_t tr = S(xr, xr, zero, 1.0), ti = zero;
+    if constexpr (CPLX) {
+      tr = S(xi, xi, tr, 1.0);
+      ti = S(xr, xi, zero, 1.0);
+      ti = S(xi, xr, ti, -1.0);
+    }
+    bool bad = false;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double err = fmax(fabs(tr[r] - ((l4 + 4 * r == l15) ? 1.0 : 0.0)), fabs(ti[r]));
+      if (in[r] && !(err < 1e-14)) bad = true;
+    }
+    if (!__any(bad)) break;
+    double trr[4] = {tr[0], tr[1], tr[2], tr[3]}, tii[4] = {ti[0], ti[1], ti[2], ti[3]};
+    d4_t yr = S(xtr, trr, zero, 1.0), yi = zero, ytr = S(trr, xtr, zero, 1.0), yti = zero;
+    if constexpr (CPLX) {
+      yr = S(xti, tii, yr, -1.0);
+      yi = S(xtr, tii, zero, 1.0);
+      yi = S(xti, trr, yi, 1.0);
+      ytr = S(tii, xti, ytr, -1.0);
+      yti = S(tii, xtr, zero, 1.0);
+      yti = S(trr, xti, yti, 1.0);
+    }
+    double ca, cb;
+    ns_scaled_coefficients(ell, ca, cb);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      xr[r] = ca * xr[r] - cb * yr[r];
+      xtr[r] = ca * xtr[r] - cb * ytr[r];
+      if constexpr (CPLX) {
+        xi[r] = ca * xi[r] - cb * yi[r];
+        xti[r] = ca * xti[r] - cb * yti[r];
+      }
+    }
+  }
+  const bool ok = it < 100;
+  // A0 R = S(A0^T, R), A0^T = conj(A0) (Hermitian): real part symmetric, imaginary part antisymmetric
+  double a_r[4], a_i[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    a_r[r] = in[r] ? A0r[(l4 + 4 * r) * p + l15] : 0.0;
+    a_i[r] = (CPLX && in[r]) ? A0i[(l4 + 4 * r) * p + l15] : 0.0;
+  }
+  d4_t wr = S(a_r, xr, zero, 1.0), wi = zero;
+  if constexpr (CPLX) {
+    wr = S(a_i, xi, wr, 1.0);
+    wi = S(a_r, xi, zero, 1.0);
+    wi = S(a_i, xr, wi, -1.0);
+  }
+  double hk = 0.0, ck = 0.0;     // this lane's share of column l15: rows l4, l4 + 4, l4 + 8, l4 + 12
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    hk += xr[r] * g_r[r];
+    ck += xr[r] * wr[r];
+    if constexpr (CPLX) {
+      hk += xi[r] * g_i[r];
+      ck += xi[r] * wi[r];
+    }
+  }
+  hk += __shfl_xor(hk, 16);
+  ck += __shfl_xor(ck, 16);
+  hk += __shfl_xor(hk, 32);
+  ck += __shfl_xor(ck, 32);
+  // every lane holds H_kk and c_k of its column k = l15 now (the four rows agree bit for bit: the additions commute)
+  const double dsum = rot_lane(rot_row_sum(hk), 0);
+  const double hmin = rot_lane(rot_row_min(l15 < p ? hk : 1.7e308), 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (in[r]) {
+      Rr[(l4 + 4 * r) * p + l15] = xr[r];
+      if constexpr (CPLX) Ri[(l4 + 4 * r) * p + l15] = xi[r];
+    }
+  }
+  if (lane < p) cvec[lane] = ck;
+  if (lane == 0) {
+    state[6] = 0.5 * hmin * inv;                  // next iteration's guess (ignored unless within (1e-6, 1))
+    const double d_old = state[2];
+    state[3] = d_old;
+    state[2] = dsum;
+    state[0] += 1.0;
+    state[5] = (double)(ok ? it : 100);
+    if (!ok || !(dsum == dsum)) state[4] = 1.0;                  // NaN / singular G
+    else if (fabs(dsum - d_old) / dsum < tol) state[1] = 1.0;    // rotation.py:62
+  }
+}
+
 // One 16 x 16 tile of T = X^H X (TSTEP) or of Y = X T (!TSTEP) with the KS k-steps unrolled: the accumulators then stay
 // in the MFMA's registers from the first to the last step (as a run-time loop the compiler moves all of them to VGPRs
 // and back every step and waits for each MFMA - 2.3x the time of the whole iteration).  (ar, ai) is the A operand at
@@ -1118,6 +1276,15 @@ __device__ __forceinline__ void varimax_polar_step(double* __restrict__ sm, cons
     }
   }
   ROT_STAMP(3);
+  static_assert(ROT_PMAX >= 16, "");
+  if (p <= 16) {
+    // one wave, everything in registers (it starts again from G in LDS; the block-wide norm is not needed)
+    __syncthreads();
+    if (tid < 64) varimax_polar_wave16_full<CPLX>(Gr, Gi, p, A0r, A0i, Rr, Ri, cvec, state, tol);
+    ROT_STAMP(4);
+    ROT_STAMP(5);
+    return;                        // (the callers synchronise before anybody reads R, c or the state)
+  }
   fro2 = block_reduce(fro2, false);
   const double inv = 1.0 / sqrt(fro2);
   for (int e = tid; e < pp; e += 256) {
