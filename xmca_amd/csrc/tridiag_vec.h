@@ -382,36 +382,61 @@ struct TrdVecWorkspace {
   DevBuf<double> band[2];     // S, T, P of the compact-WY precomputation (band layout), re / im
   DevBuf<double> TV[2];       // T V^H (n x ldv planes)
   TrdBackPlan plan;
+  // the compact-WY factors depend on the reflectors alone: they are built on a second stream while the eigenvalues and the
+  // vectors of the tridiagonal matrix - two kernels that leave most of the chip idle - run on the caller's
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  GemmWorkspace side_gws;
+  bool prepared = false;
+  void side_init() {
+    if (side) return;
+    XMCA_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    XMCA_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    XMCA_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+  }
+  ~TrdVecWorkspace() {
+    if (side) {
+      (void)hipStreamSynchronize(side);
+      (void)hipEventDestroy(ev_fork);
+      (void)hipEventDestroy(ev_join);
+      (void)hipStreamDestroy(side);
+    }
+  }
+  TrdVecWorkspace() = default;
+  TrdVecWorkspace(const TrdVecWorkspace&) = delete;
+  TrdVecWorkspace& operator=(const TrdVecWorkspace&) = delete;
   DevBuf<double> lam_asc;
   DevBuf<unsigned long long> orth;
   double last_orth = 0.0;     // max |Z^H Z - I| before the clean-up of the last call
   int ns_steps = 0;
 };
 
-// Eigenvectors of the matrix reduced by trd_reduce(..., keep_reflectors = true): Zr / Zi (n x ldz planes) get row i =
-// conj(u_i) for the eigenvalues in DESCENDING order (the layout of hermitian_evd).  Returns false when the vectors of the
-// tridiagonal are too far from orthonormal to be repaired (clusters) - the caller then uses the Jacobi solver.
-inline bool trd_eigenvectors(hipStream_t st, TrdWorkspace& ws, TrdVecWorkspace& vw, GemmWorkspace& gws, const TrdParams& P, bool cplx,
-                             double* Zr, double* Zi, int64_t ldz) {
+// T of every super-block and T V^H from the reflectors of trd_reduce(..., keep_reflectors = true), queued on the workspace's
+// second stream behind everything `st` holds so far; trd_eigenvectors joins it in front of the back-transformation.
+inline void trd_wy_prepare(hipStream_t st, TrdVecWorkspace& vw, const TrdParams& P, bool cplx) {
   const int n = P.n;
   const int64_t ldv = P.ld;                                   // reflectors: row j = v_j, zero outside its support j+1 .. n-1
   constexpr int SBK = TRD_SBK;
-  const int64_t ld = ((int64_t)n + 15) & ~(int64_t)15;
-  const size_t plane = (size_t)n * ld;
-  double* Yr = vw.Y[0].ensure(plane);
-  double* Yi = cplx ? vw.Y[1].ensure(plane) : nullptr;
-  double* Wr = vw.Wk[0].ensure(plane);
-  double* Wi = cplx ? vw.Wk[1].ensure(plane) : nullptr;
-  hipLaunchKernelGGL(trd_twisted_kernel, dim3(ceil_div(n, 64)), dim3(128), 0, st, P.d, P.e, n, vw.lam_asc.get(), Wr, Yr, ld);
-  XMCA_HIP(hipGetLastError());
-  if (cplx) XMCA_HIP(hipMemsetAsync(Yi, 0, sizeof(double) * plane, st));
   const int nref = n - 1;
-  if (nref > 0) {
+  if (vw.prepared && vw.side) XMCA_HIP(hipStreamSynchronize(vw.side));    // (an earlier call left without joining: an exception in between)
+  vw.prepared = false;
+  if (nref <= 0) return;
+  vw.side_init();
+  if (vw.plan.n != n) vw.plan.build(st, n);
+  // Everything the second stream touches is allocated OUTSIDE the handle's pool: a pool hands a released block to the next
+  // taker on the strength of stream order, which holds for one stream only (a split-K workspace that grows between two GEMMs
+  // of this function would otherwise go back to the pool - and to a kernel on `st` - while the first GEMM still writes it).
+  // hipMalloc / hipFree synchronise the device; the sizes settle after the first call of a given order.
+  PoolScope no_pool(nullptr);
+  XMCA_HIP(hipEventRecord(vw.ev_fork, st));
+  XMCA_HIP(hipStreamWaitEvent(vw.side, vw.ev_fork, 0));
+  {
+    hipStream_t st = vw.side;                                 // (everything below runs on the second stream)
+    GemmWorkspace& gws = vw.side_gws;
     // ---- T of every super-block and T V^H, from the reflectors alone ----
     // Band layout: element (r, q) of S / T / P at [r * SBK + q] with ABSOLUTE indices - only entries of one diagonal
     // super-block are ever touched, so super-block s sits at s * (SBK * SBK + SBK) and the three matrices are ordinary GEMM
     // operands with leading dimension SBK; rows and columns past n stay zero.
-    if (vw.plan.n != n) vw.plan.build(st, n);
     const TrdBackPlan& pl = vw.plan;
     const int nsb = ceil_div(n, SBK), npad = nsb * SBK;
     const size_t bsz = (size_t)nsb * ((size_t)SBK * SBK + SBK) + SBK;
@@ -438,6 +463,35 @@ inline bool trd_eigenvectors(hipStream_t st, TrdWorkspace& ws, TrdVecWorkspace& 
     double* TVi = cplx ? vw.TV[1].ensure((size_t)n * ldv) : nullptr;
     cgemm<double>(st, gws, Tr_, Ti_, SBK, true, false, P.Vr, P.Vi, ldv, true, true, TVr, TVi, ldv, n, n, n, 1.0, nullptr, nullptr, false, 0.0,
                   &pl.tv);
+  }
+  XMCA_HIP(hipEventRecord(vw.ev_join, vw.side));
+  vw.prepared = true;
+}
+
+// Eigenvectors of the matrix reduced by trd_reduce(..., keep_reflectors = true): Zr / Zi (n x ldz planes) get row i =
+// conj(u_i) for the eigenvalues in DESCENDING order (the layout of hermitian_evd).  Returns false when the vectors of the
+// tridiagonal are too far from orthonormal to be repaired (clusters) - the caller then uses the Jacobi solver.
+inline bool trd_eigenvectors(hipStream_t st, TrdWorkspace& ws, TrdVecWorkspace& vw, GemmWorkspace& gws, const TrdParams& P, bool cplx,
+                             double* Zr, double* Zi, int64_t ldz) {
+  const int n = P.n;
+  const int64_t ldv = P.ld;                                   // reflectors: row j = v_j, zero outside its support j+1 .. n-1
+  constexpr int SBK = TRD_SBK;
+  const int64_t ld = ((int64_t)n + 15) & ~(int64_t)15;
+  const size_t plane = (size_t)n * ld;
+  double* Yr = vw.Y[0].ensure(plane);
+  double* Yi = cplx ? vw.Y[1].ensure(plane) : nullptr;
+  double* Wr = vw.Wk[0].ensure(plane);
+  double* Wi = cplx ? vw.Wk[1].ensure(plane) : nullptr;
+  hipLaunchKernelGGL(trd_twisted_kernel, dim3(ceil_div(n, 64)), dim3(128), 0, st, P.d, P.e, n, vw.lam_asc.get(), Wr, Yr, ld);
+  XMCA_HIP(hipGetLastError());
+  if (cplx) XMCA_HIP(hipMemsetAsync(Yi, 0, sizeof(double) * plane, st));
+  const int nref = n - 1;
+  if (nref > 0) {
+    XMCA_CHECK(vw.prepared, XMCA_ERR_STATE, "trd_eigenvectors: trd_wy_prepare has not run");
+    vw.prepared = false;
+    XMCA_HIP(hipStreamWaitEvent(st, vw.ev_join, 0));      // T V^H of every super-block is ready (second stream)
+    const double* TVr = vw.TV[0].get();
+    const double* TVi = cplx ? vw.TV[1].get() : nullptr;
     // ---- Z = H_0 H_1 ... H_{n-2} Yt, super-blocks from the last to the first:  X = (T V^H) Z,  Z -= V X ----
     double* sm = vw.small.ensure(2 * (size_t)SBK * ld);
     double* Xr = sm; double* Xi = cplx ? Xr + (size_t)SBK * ld : nullptr;
