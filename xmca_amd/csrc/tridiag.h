@@ -989,9 +989,9 @@ __global__ void trd_copy_kernel(const double* __restrict__ Ar, const double* __r
 }
 
 // ---- all eigenvalues of the symmetric tridiagonal (d, e) by Sturm multisection ------------------------------------
-// 16 lanes per eigenvalue: count(x) = number of eigenvalues below x at 16 interior points of the bracket per pass (LDL^T
-// recurrence with the pivmin safeguard of LAPACK dstebz; the reciprocal is a hardware seed + two Newton steps, i.e. the
-// count of a matrix a few ulps away).  14 passes shrink the Gershgorin interval by 17^14 = 1.7e17.
+// 16 lanes per eigenvalue: count(x) = number of eigenvalues below x at 16 interior points of the bracket per pass (sign
+// changes of the leading principal minors by their three-term recurrence: one dependent FMA per row, no division, no
+// compare in the chain).  14 passes shrink the Gershgorin interval by 17^14 = 1.7e17.
 // lam_desc[n-1-k] = eigenvalue k (ascending) / scale factor.  flag[0] != 0: non-finite input.
 constexpr int TRD_BIS_THREADS = 256;
 __global__ __launch_bounds__(TRD_BIS_THREADS) void trd_bisect_kernel(const double* __restrict__ d, const double* __restrict__ e, int n,
@@ -1001,36 +1001,31 @@ __global__ __launch_bounds__(TRD_BIS_THREADS) void trd_bisect_kernel(const doubl
   double* sd = bis_lds;
   double* se2 = bis_lds + n;
   const int tid = threadIdx.x;
-  double gl = 1.7e308, gu = -1.7e308, emax = 0.0;
+  double gl = 1.7e308, gu = -1.7e308;
   bool bad = false;
   for (int i = tid; i < n; i += TRD_BIS_THREADS) {
     const double di = d[i];
     const double el = i > 0 ? e[i - 1] : 0.0, er = i < n - 1 ? e[i] : 0.0;
     if (!(fabs(di) <= 1.7e308) || !(fabs(er) <= 1.7e308)) bad = true;
     sd[i] = di;
-    se2[i] = er * er;                          // se2[i] couples i and i+1
+    // se2[i] couples i and i+1.  Floor 2^-200 (the matrix is scaled to norm <= 1: a perturbation of 8e-31 of an entry) so
+    // that an exactly split matrix (e = 0) cannot leave two consecutive zero minors behind - see the count below
+    se2[i] = fmax(er * er, 0x1p-200);
     const double r = fabs(el) + fabs(er);
     gl = fmin(gl, di - r);
     gu = fmax(gu, di + r);
-    emax = fmax(emax, er * er);
   }
   for (int o = 32; o > 0; o >>= 1) {
     gl = fmin(gl, __shfl_xor(gl, o));
     gu = fmax(gu, __shfl_xor(gu, o));
-    emax = fmax(emax, __shfl_xor(emax, o));
   }
   if (__any(bad) && flag) { if ((tid & 63) == 0) atomicOr(flag, 1); }
   if ((tid & 63) == 0) { red[0][tid >> 6] = gl; red[1][tid >> 6] = gu; }
   __syncthreads();
   for (int w = 0; w < TRD_BIS_THREADS / 64; ++w) { gl = fmin(gl, red[0][w]); gu = fmax(gu, red[1][w]); }
-  __syncthreads();
-  if ((tid & 63) == 0) red[0][tid >> 6] = emax;
-  __syncthreads();
-  for (int w = 0; w < TRD_BIS_THREADS / 64; ++w) emax = fmax(emax, red[0][w]);
   const double bnorm = fmax(fabs(gl), fabs(gu));
   gl -= 2.2e-16 * bnorm * n + 1e-300;
   gu += 2.2e-16 * bnorm * n + 1e-300;
-  const double pivmin = 2.3e-308 * fmax(1.0, emax);
   const int grp = tid >> 4, l = tid & 15;
   const int k = blockIdx.x * (TRD_BIS_THREADS / 16) + grp;       // eigenvalue index, ascending
   const bool live = k < n;
@@ -1039,31 +1034,50 @@ __global__ __launch_bounds__(TRD_BIS_THREADS) void trd_bisect_kernel(const doubl
   for (int pass = 0; pass < 14; ++pass) {
     const double x = lo + (hi - lo) * ((double)(l + 1) * (1.0 / 17.0));
     // Sturm count by the three-term recurrence of the leading principal minors, p_{i+1} = (d_i - x) p_i - e_{i-1}^2 p_{i-1}:
-    // count = sign changes along p_0 = 1, p_1, ..., p_n (a zero takes the sign opposite to its predecessor, the pivmin
-    // convention of dstebz).  One dependent FMA per row instead of a division; the pair (p_i, p_{i-1}) is rescaled by a
-    // power of two every eight rows (growth per row is bounded by ~5 for the scaled matrix, so neither overflows within
-    // eight rows, and the larger of the two is kept near 1).
+    // count = sign changes along p_0 = 1, p_1, ..., p_n.  One dependent FMA per row instead of a division; the pair
+    // (p_i, p_{i-1}) is rescaled by a power of two every eight rows (growth per row is bounded by ~5 for the scaled matrix, so
+    // neither overflows within eight rows, and the larger of the two is kept near 1).
+    // An exact zero needs no fix-up in the chain (round 4: the compare + selects were a third of the row's instructions and
+    // sat on its dependent path): e^2 has a floor (below), so a zero p_i is followed by p_{i+1} = -e_i^2 p_{i-1} != 0 of the
+    // sign opposite to p_{i-1} - exactly one sign change over the two steps whichever sign the zero is given, the same count
+    // as dstebz's "a zero takes the sign opposite to its predecessor".  Signs are compared on the high words.
     double pm = 1.0, pc = sd[0] - x;
-    if (pc == 0.0) pc = -pivmin;
-    int cnt = pc < 0.0;
+    unsigned int sc = (unsigned int)__double2hiint(pc);
+    int cnt = (int)(sc >> 31);
     int i = 1;
+    // (the operands of the NEXT eight rows are requested before the current eight are used: the LDS latency stays off the chain)
+    double dv[8], ev[8];
+    if (i + 8 <= n) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { dv[u] = sd[i + u]; ev[u] = se2[i + u - 1]; }
+    }
     for (; i + 8 <= n; i += 8) {
+      double dn[8], en[8];
+      const int inext = i + 16 <= n ? i + 8 : i;           // (the last block reads its own rows again)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { dn[u] = sd[inext + u]; en[u] = se2[inext + u - 1]; }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        double pn = fma(sd[i + u] - x, pc, -se2[i + u - 1] * pm);
-        if (pn == 0.0) pn = pc < 0.0 ? 4.9e-324 : -4.9e-324;
-        cnt += (pn < 0.0) != (pc < 0.0);
+        const double pn = fma(dv[u] - x, pc, -(ev[u] * pm));
+        const unsigned int sn = (unsigned int)__double2hiint(pn);
+        cnt += (int)((sn ^ sc) >> 31);
+        sc = sn;
         pm = pc;
         pc = pn;
       }
-      const int ex = __builtin_amdgcn_frexp_exp(fmax(fabs(pc), fabs(pm)));
+      const double mx = fmax(fabs(pc), fabs(pm));
+      if (mx == 0.0) pc = (sc >> 31) ? -1.0 : 1.0;            // (both underflowed: start again with the sign kept - not reachable with the floor on e^2)
+      const int ex = __builtin_amdgcn_frexp_exp(mx);
       pc = ldexp(pc, -ex);
       pm = ldexp(pm, -ex);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { dv[u] = dn[u]; ev[u] = en[u]; }
     }
     for (; i < n; ++i) {
-      double pn = fma(sd[i] - x, pc, -se2[i - 1] * pm);
-      if (pn == 0.0) pn = pc < 0.0 ? 4.9e-324 : -4.9e-324;
-      cnt += (pn < 0.0) != (pc < 0.0);
+      const double pn = fma(sd[i] - x, pc, -(se2[i - 1] * pm));
+      const unsigned int sn = (unsigned int)__double2hiint(pn);
+      cnt += (int)((sn ^ sc) >> 31);
+      sc = sn;
       pm = pc;
       pc = pn;
     }
