@@ -164,7 +164,7 @@ inline void hermitian_evd(hipStream_t st, EvdWorkspace& ws, const double* Ar, co
   const int trd_vec_min_n = [] { const char* e = std::getenv("XMCA_TRIDIAG_VEC_MIN_N"); return e ? std::atoi(e) : 768; }();
   if (Zr && !nearly_diagonal && trd_enabled() && n >= trd_vec_min_n && trd_fits(n, Ai != nullptr)) {
     TrdParams P = trd_reduce(st, ws.trd, Ar, Ai, n, lda, true);
-    trd_wy_prepare(st, ws.trdv, P, Ai != nullptr);          // (second stream: overlaps the two kernels below)
+    trd_wy_prepare(st, ws.trdv, ws.gws, P, Ai != nullptr);  // (from the second call on: on a second stream, under the two kernels below)
     std::vector<double> lam_t;
     trd_eigenvalues(st, ws.trd, P, lam_t, lam_dev, ws.lam_tmp, ws.trdv.lam_asc.ensure((size_t)n));
     if (trd_eigenvectors(st, ws.trd, ws.trdv, ws.gws, P, Ai != nullptr, Zr, Zi, ldz)) {

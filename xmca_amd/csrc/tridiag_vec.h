@@ -387,7 +387,8 @@ struct TrdVecWorkspace {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   GemmWorkspace side_gws;
-  bool prepared = false;
+  bool prepared = false, joined = true;
+  int calls = 0;
   void side_init() {
     if (side) return;
     XMCA_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
@@ -413,7 +414,7 @@ struct TrdVecWorkspace {
 
 // T of every super-block and T V^H from the reflectors of trd_reduce(..., keep_reflectors = true), queued on the workspace's
 // second stream behind everything `st` holds so far; trd_eigenvectors joins it in front of the back-transformation.
-inline void trd_wy_prepare(hipStream_t st, TrdVecWorkspace& vw, const TrdParams& P, bool cplx) {
+inline void trd_wy_prepare(hipStream_t st, TrdVecWorkspace& vw, GemmWorkspace& gws_main, const TrdParams& P, bool cplx) {
   const int n = P.n;
   const int64_t ldv = P.ld;                                   // reflectors: row j = v_j, zero outside its support j+1 .. n-1
   constexpr int SBK = TRD_SBK;
@@ -421,18 +422,25 @@ inline void trd_wy_prepare(hipStream_t st, TrdVecWorkspace& vw, const TrdParams&
   if (vw.prepared && vw.side) XMCA_HIP(hipStreamSynchronize(vw.side));    // (an earlier call left without joining: an exception in between)
   vw.prepared = false;
   if (nref <= 0) return;
-  vw.side_init();
   if (vw.plan.n != n) vw.plan.build(st, n);
+  // Creating a stream costs ~10 ms (measured: hipStreamCreateWithFlags inside the first solve of a process) - thirty solves'
+  // worth of what the overlap saves.  The first call of a workspace therefore stays on `st`; from the second call on the
+  // workspace belongs to somebody who solves repeatedly, and the second stream is made.
+  const bool use_side = vw.side != nullptr || ++vw.calls >= 2;
+  if (use_side) vw.side_init();
   // Everything the second stream touches is allocated OUTSIDE the handle's pool: a pool hands a released block to the next
   // taker on the strength of stream order, which holds for one stream only (a split-K workspace that grows between two GEMMs
   // of this function would otherwise go back to the pool - and to a kernel on `st` - while the first GEMM still writes it).
-  // hipMalloc / hipFree synchronise the device; the sizes settle after the first call of a given order.
-  PoolScope no_pool(nullptr);
-  XMCA_HIP(hipEventRecord(vw.ev_fork, st));
-  XMCA_HIP(hipStreamWaitEvent(vw.side, vw.ev_fork, 0));
+  // hipFree synchronises the device; the sizes settle after the first call of a given order.
+  PoolScope scope(use_side ? nullptr : current_pool());
+  if (use_side) {
+    XMCA_HIP(hipEventRecord(vw.ev_fork, st));
+    XMCA_HIP(hipStreamWaitEvent(vw.side, vw.ev_fork, 0));
+  }
   {
-    hipStream_t st = vw.side;                                 // (everything below runs on the second stream)
-    GemmWorkspace& gws = vw.side_gws;
+    hipStream_t st_main = st;
+    hipStream_t st = use_side ? vw.side : st_main;            // (everything below runs on the second stream when there is one)
+    GemmWorkspace& gws = use_side ? vw.side_gws : gws_main;
     // ---- T of every super-block and T V^H, from the reflectors alone ----
     // Band layout: element (r, q) of S / T / P at [r * SBK + q] with ABSOLUTE indices - only entries of one diagonal
     // super-block are ever touched, so super-block s sits at s * (SBK * SBK + SBK) and the three matrices are ordinary GEMM
@@ -464,7 +472,8 @@ inline void trd_wy_prepare(hipStream_t st, TrdVecWorkspace& vw, const TrdParams&
     cgemm<double>(st, gws, Tr_, Ti_, SBK, true, false, P.Vr, P.Vi, ldv, true, true, TVr, TVi, ldv, n, n, n, 1.0, nullptr, nullptr, false, 0.0,
                   &pl.tv);
   }
-  XMCA_HIP(hipEventRecord(vw.ev_join, vw.side));
+  if (use_side) XMCA_HIP(hipEventRecord(vw.ev_join, vw.side));
+  vw.joined = !use_side;
   vw.prepared = true;
 }
 
@@ -489,7 +498,8 @@ inline bool trd_eigenvectors(hipStream_t st, TrdWorkspace& ws, TrdVecWorkspace& 
   if (nref > 0) {
     XMCA_CHECK(vw.prepared, XMCA_ERR_STATE, "trd_eigenvectors: trd_wy_prepare has not run");
     vw.prepared = false;
-    XMCA_HIP(hipStreamWaitEvent(st, vw.ev_join, 0));      // T V^H of every super-block is ready (second stream)
+    if (!vw.joined) XMCA_HIP(hipStreamWaitEvent(st, vw.ev_join, 0));      // T V^H of every super-block is ready (second stream)
+    vw.joined = true;
     const double* TVr = vw.TV[0].get();
     const double* TVi = cplx ? vw.TV[1].get() : nullptr;
     // ---- Z = H_0 H_1 ... H_{n-2} Yt, super-blocks from the last to the first:  X = (T V^H) Z,  Z -= V X ----
