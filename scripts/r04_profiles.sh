@@ -24,7 +24,7 @@ import bench
 tag, cmd = sys.argv[1], sys.argv[2]
 out = {}
 def key(name):
-    for k in ("trd_resident_kernel", "trd_step_kernel", "trd_bisect_kernel", "trd_twisted_kernel", "trd_wy_solve_kernel", "gemm_kernel",
+    for k in ("trd_resident_kernel", "trd_step_kernel", "trd_bisect_kernel", "trd_twisted_kernel", "trd_wy_tinv_kernel", "gemm_kernel",
               "varimax_persistent", "jacobi_fused_round"):
         if k in name: return k
     return None

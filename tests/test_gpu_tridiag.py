@@ -47,10 +47,13 @@ def test_eigenvalues_only_match_lapack(hip, monkeypatch, n, cplx, resident):
     assert np.array_equal(lam, again)                       # fixed summation order: the same bits
 
 
-@pytest.mark.parametrize("n,cplx", [(130, False), (193, True), (1000, False), (900, True)])
+@pytest.mark.parametrize("n,cplx", [(130, False), (193, True), (514, False), (577, True), (1000, False), (1025, True), (1100, False)])
 def test_back_transformation_with_short_last_blocks(hip, monkeypatch, n, cplx):
-    """Blocks of 128 reflectors (the 128 x 128 WY system solved as two halves of 64 with one product in between); the last
-    block is shorter, here also shorter than 64 or just above it: a full orthonormal decomposition all the same."""
+    """Super-blocks of 512 reflectors whose compact-WY factors are built ahead of the loop (64 x 64 inverses, then the
+    levels 64 -> 128 -> 256 -> 512 as block-sparse GEMM launches); the last super-block is shorter - a single reflector
+    (n = 514), less than one block tile, exactly full (n = 1025) - and levels whose second half is empty: a full orthonormal
+    decomposition all the same.  The second call of a workspace builds the factors on the eigensolver's second stream: the
+    same bits."""
     monkeypatch.setenv("XMCA_TRIDIAG_VEC_MIN_N", "2")
     G = _gram(n, cplx)
     lam, U = hip.eigh(G)
@@ -59,6 +62,10 @@ def test_back_transformation_with_short_last_blocks(hip, monkeypatch, n, cplx):
     assert np.max(np.abs(lam - ref)) < 1e-13 * ref[0]
     assert np.max(np.abs(U.conj().T @ U - np.eye(n))) < 1e-12
     assert np.max(np.linalg.norm(G @ U - U * lam, axis=0)) < 1e-12 * ref[0]
+    for _ in range(2):
+        lam2, U2 = hip.eigh(G)
+        assert hip.last_eigh_info["tridiag"] == 1
+        assert np.array_equal(lam, lam2) and np.array_equal(U, U2)
 
 
 @pytest.mark.parametrize("resident", ["tagged", "flags", "0"])
