@@ -115,7 +115,10 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double* __restrict__ Gr,
 template <bool CPLX>
 __global__ __launch_bounds__(64) void chol_trsm_kernel(double* __restrict__ Gr, double* __restrict__ Gi, int64_t ld, int k0, int rest,
                                                        const double* __restrict__ Lt_r, const double* __restrict__ Lt_i,
-                                                       const double* __restrict__ dinv) {
+                                                       const double* __restrict__ dinv, double* __restrict__ S1 = nullptr,
+                                                       double* __restrict__ S2 = nullptr, int64_t lds = 0) {
+  // S1 / S2 (complex, optional): the panel once more as the stacked real operands [Re R; Im R] and [Im R; -Re R] (128 x rest,
+  // pitch lds) - with them the Hermitian rank-64 update is two real products of depth 128 instead of four of depth 64
   __shared__ double Lr[CHOL_NB][CHOL_NB], Li[CPLX ? CHOL_NB : 1][CPLX ? CHOL_NB : 1];
   __shared__ double Yr[CHOL_NB][64], Yi[CPLX ? CHOL_NB : 1][CPLX ? 64 : 1];
   __shared__ double dv_s[CHOL_NB];
@@ -182,6 +185,18 @@ __global__ __launch_bounds__(64) void chol_trsm_kernel(double* __restrict__ Gr, 
     for (int i = 0; i < CHOL_NB; ++i) {
       Gr[base + (int64_t)i * ld] = Yr[i][lane];
       if constexpr (CPLX) Gi[base + (int64_t)i * ld] = Yi[i][lane];
+    }
+    if constexpr (CPLX) {
+      if (S1) {
+#pragma unroll 16
+        for (int i = 0; i < CHOL_NB; ++i) {
+          const double yr = Yr[i][lane], yi = Yi[i][lane];
+          S1[(int64_t)i * lds + c] = yr;
+          S1[(int64_t)(CHOL_NB + i) * lds + c] = yi;
+          S2[(int64_t)i * lds + c] = yi;
+          S2[(int64_t)(CHOL_NB + i) * lds + c] = -yr;
+        }
+      }
     }
   }
 }
@@ -281,6 +296,10 @@ inline bool cholesky_upper(hipStream_t st, GemmWorkspace& ws, double* Gr, double
   DevBuf<int> fail;
   lt_r.ensure((size_t)CHOL_NB * CHOL_NB);
   if (cplx) lt_i.ensure((size_t)CHOL_NB * CHOL_NB);
+  DevBuf<double> stack;
+  const int64_t lds = ((int64_t)n + 15) & ~(int64_t)15;
+  double* s1 = cplx ? stack.ensure((size_t)4 * CHOL_NB * lds) : nullptr;
+  double* s2 = cplx ? s1 + (size_t)2 * CHOL_NB * lds : nullptr;
   dinv.ensure(CHOL_NB);
   XMCA_HIP(hipMemsetAsync(mx.ensure(1), 0, sizeof(unsigned long long), st));
   XMCA_HIP(hipMemsetAsync(fail.ensure(1), 0, sizeof(int), st));
@@ -298,7 +317,7 @@ inline bool cholesky_upper(hipStream_t st, GemmWorkspace& ws, double* Gr, double
       hipLaunchKernelGGL((chol_diag_kernel<true>), dim3(1), dim3(256), 0, st, Gr, Gi, ld, k0, nb, lt_r.get(), lt_i.get(), dinv.get(), fail.get());
       if (rest > 0)
         hipLaunchKernelGGL((chol_trsm_kernel<true>), dim3(ceil_div(rest, 64)), dim3(64), 0, st, Gr, Gi, ld, k0, rest, lt_r.get(), lt_i.get(),
-                           dinv.get());
+                           dinv.get(), s1, s2, lds);
     } else {
       hipLaunchKernelGGL((chol_diag_kernel<false>), dim3(1), dim3(256), 0, st, Gr, (double*)nullptr, ld, k0, nb, lt_r.get(),
                          (double*)nullptr, dinv.get(), fail.get());
@@ -310,8 +329,19 @@ inline bool cholesky_upper(hipStream_t st, GemmWorkspace& ws, double* Gr, double
     if (rest <= 0) break;
     const int64_t o12 = (int64_t)k0 * ld + k0 + nb, o22 = (int64_t)(k0 + nb) * ld + k0 + nb;
     // A22 -= R12^H R12   (upper block triangle, mirrored)
-    cgemm<double>(st, ws, Gr + o12, cplx ? Gi + o12 : nullptr, ld, false, true, Gr + o12, cplx ? Gi + o12 : nullptr, ld, true, false,
-                  Gr + o22, cplx ? Gi + o22 : nullptr, ld, rest, rest, nb, -1.0, nullptr, nullptr, true, 1.0);
+    if (cplx) {
+      // Re: S1^T S1,  Im: S1^T S2  with S1 = [Re R12; Im R12], S2 = [Im R12; -Re R12] (written by the substitution kernel):
+      // two launches of depth 128 instead of four of depth 64 - the updates of a 2500-row factorisation are launch-bound
+      GemmOpts o;
+      o.a_kfast = false; o.b_nfast = true; o.alpha = -1.0; o.beta = 1.0; o.upper_only = true;
+      o.mirror = 1;
+      gemm<double, double>(st, ws, s1, lds, s1, lds, Gr + o22, ld, rest, rest, 2 * CHOL_NB, o);
+      o.mirror = -1;
+      gemm<double, double>(st, ws, s1, lds, s2, lds, Gi + o22, ld, rest, rest, 2 * CHOL_NB, o);
+    } else {
+      cgemm<double>(st, ws, Gr + o12, nullptr, ld, false, true, Gr + o12, nullptr, ld, true, false, Gr + o22, nullptr, ld, rest, rest, nb, -1.0,
+                    nullptr, nullptr, true, 1.0);
+    }
   }
   hipLaunchKernelGGL(chol_zero_lower_kernel, ew_grid((int64_t)n * n), dim3(EW_BLOCK), 0, st, Gr, Gi, ld, n);
   XMCA_HIP(hipGetLastError());
