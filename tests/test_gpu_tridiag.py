@@ -68,6 +68,32 @@ def test_back_transformation_with_short_last_blocks(hip, monkeypatch, n, cplx):
         assert np.array_equal(lam, lam2) and np.array_equal(U, U2)
 
 
+@pytest.mark.parametrize("scale", [1e6, 1.0, 1e-6])
+@pytest.mark.parametrize("cplx", [False, True])
+def test_indefinite_matrix_with_zero_diagonal(hip, monkeypatch, cplx, scale):
+    """xmca_eigh is a general Hermitian solver: an indefinite matrix whose diagonal is exactly zero and whose off-diagonal
+    entries are large or tiny.  The working copy is scaled by max |a_ij| (the diagonal alone gave f = 1 here, and the
+    rescaling interval of the Sturm count and the pivot floors of the twisted factorisation assume entries below 1)."""
+    monkeypatch.setenv("XMCA_TRIDIAG_VEC_MIN_N", "2")
+    monkeypatch.setenv("XMCA_TRIDIAG_MIN_N", "2")
+    rng = np.random.default_rng(77)
+    n = 400
+    B = rng.standard_normal((n, n))
+    if cplx:
+        B = B + 1j * rng.standard_normal((n, n))
+    A = (B + B.conj().T) * scale
+    np.fill_diagonal(A, 0.0)
+    ref = np.linalg.eigvalsh(A)[::-1]
+    nrm = np.max(np.abs(ref))
+    lam, _ = hip.eigh(A, vectors=False)
+    assert hip.last_eigh_info["tridiag"] == 1
+    assert np.max(np.abs(lam - ref)) < 1e-13 * nrm
+    lam, U = hip.eigh(A)
+    assert np.max(np.abs(lam - ref)) < 1e-13 * nrm
+    assert np.max(np.abs(U.conj().T @ U - np.eye(n))) < 1e-12
+    assert np.max(np.linalg.norm(A @ U - U * lam, axis=0)) < 1e-12 * nrm
+
+
 @pytest.mark.parametrize("resident", ["tagged", "flags", "0"])
 @pytest.mark.parametrize("n,cplx", [(70, False), (200, True), (777, False), (1000, True), (1500, False)])
 def test_eigenvectors_match_lapack(hip, monkeypatch, n, cplx, resident):

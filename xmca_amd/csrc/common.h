@@ -47,8 +47,8 @@ struct Error : std::runtime_error {
 // points, lane threads); a DevBuf remembers the pool it came from and returns there from any thread.
 // Blocks above `keep_limit` in total (XMCA_POOL_LIMIT_GB, default 16) are freed straight away; XMCA_POOL=0 switches
 // pooling off; xmca_trim_pool returns what is held.  Every pool of the process is registered: when hipMalloc fails, the
-// blocks parked in ALL pools (sibling lanes, the parent handle, other handles) are given back before giving up - hipFree
-// synchronises the device, so a block another stream released earlier is safe to free here.  The lane pools of
+// blocks parked in ALL pools (sibling lanes, the parent handle, other handles) are given back before giving up - behind a
+// hipDeviceSynchronize, so a block another stream released earlier is safe to free here.  The lane pools of
 // rule_n / bootstrap are emptied when their call ends if they hold more than 4 GB (run_lanes, xmca_hip.cpp).
 struct DevPool {
   struct Registry {
@@ -64,6 +64,10 @@ struct DevPool {
     registry().pools.push_back(this);
   }
   static void trim_all() {
+    // Blocks parked in OTHER pools may still be read by work queued on their streams: wait for the device before any of
+    // them is freed (advisor, round 3: this used to rest on hipFree's implicit synchronisation alone).  The registry stays
+    // locked for the loop - a pool must not be destroyed under it - but no longer across a device-wide wait per block.
+    (void)hipDeviceSynchronize();
     std::lock_guard<std::mutex> g(registry().mu);
     for (DevPool* p : registry().pools) p->trim();
   }

@@ -167,7 +167,16 @@ inline void hermitian_evd(hipStream_t st, EvdWorkspace& ws, const double* Ar, co
     trd_wy_prepare(st, ws.trdv, ws.gws, P, Ai != nullptr);  // (from the second call on: on a second stream, under the two kernels below)
     std::vector<double> lam_t;
     trd_eigenvalues(st, ws.trd, P, lam_t, lam_dev, ws.lam_tmp, ws.trdv.lam_asc.ensure((size_t)n));
-    if (trd_eigenvectors(st, ws.trd, ws.trdv, ws.gws, P, Ai != nullptr, Zr, Zi, ldz)) {
+    // Eigenvalues that coincide to the last bit of the largest one (a null space of dimension > 1: repeated samples, low-rank
+    // fields) are not resolved by the twisted vectors - the clean-up would find that out only after the back-transformation
+    // and two n^3 products (advisor, round 3); they are on the host already, so the sweeps below start right away.
+    bool repeated = false;
+    {
+      const double lmax = n > 0 ? std::max(std::fabs(lam_t.front()), std::fabs(lam_t.back())) : 0.0;
+      for (int i = 0; i + 1 < n && !repeated; ++i) repeated = lam_t[(size_t)i] - lam_t[(size_t)i + 1] <= 2.2e-16 * lmax;
+      if (repeated && xmca_trace("solve")) std::fprintf(stderr, "xmca: eigh n = %d: repeated eigenvalues - block Jacobi instead of twisted vectors\n", n);
+    }
+    if (!repeated && trd_eigenvectors(st, ws.trd, ws.trdv, ws.gws, P, Ai != nullptr, Zr, Zi, ldz)) {
       XMCA_HIP(hipStreamSynchronize(st));
       lam_host = lam_t;
       if (info) {

@@ -947,34 +947,37 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
   }
 }
 
-// working copy: W = f * A (f a power of two from max |a_ii|: exact), rows padded to ld with zeros
-__global__ void trd_maxdiag_kernel(const double* __restrict__ Ar, int n, int64_t lda, double* scal) {
-  __shared__ double red[256];
+// working copy: W = f * A, f a power of two (exact) from max |a_ij| over the WHOLE matrix (max(|re|, |im|) for complex
+// entries): the entries of the scaled matrix are then below 1 in magnitude and its norm below n whatever the input - the
+// growth bound behind the eight-row rescaling of trd_bisect_kernel and the pivot floors of trd_twisted_kernel hold for
+// indefinite matrices with a small diagonal too (advisor, round 3: the diagonal alone was used; for the positive
+// semi-definite Gram matrices of the path |a_ij| <= max a_ii, so their scale factor - and every bit downstream - is unchanged).
+// acc[0]: the maximum as a bit pattern (non-negative doubles order like their patterns), acc[1] != 0: a non-finite entry.
+__global__ __launch_bounds__(256) void trd_maxabs_kernel(const double* __restrict__ Ar, const double* __restrict__ Ai, int n, int64_t lda,
+                                                         unsigned long long* __restrict__ acc) {
   double m = 0.0;
   bool bad = false;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const double a = Ar[(int64_t)i * lda + i];
-    if (!(fabs(a) <= 1.7e308)) bad = true;
-    m = fmax(m, fabs(a));
-  }
-  red[threadIdx.x] = bad ? NAN : m;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double g = 0.0;
-    bool nan = false;
-    for (int t = 0; t < (int)blockDim.x; ++t) {
-      if (red[t] != red[t]) nan = true;
-      else g = fmax(g, red[t]);
+  for (int r = blockIdx.x; r < n; r += gridDim.x)
+    for (int c = threadIdx.x; c < n; c += 256) {
+      const double a = fabs(Ar[(int64_t)r * lda + c]), b = Ai ? fabs(Ai[(int64_t)r * lda + c]) : 0.0;
+      if (!(a <= 1.7e308) || !(b <= 1.7e308)) bad = true;
+      m = fmax(m, fmax(a, b));
     }
-    double f = 1.0;
-    if (g > 0.0 && !nan) {
-      int ex;
-      frexp(g, &ex);
-      f = ldexp(1.0, -ex);               // f * g in [0.5, 1)
-    }
-    scal[0] = f;
-    scal[1] = nan ? 1.0 : 0.0;
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+  if (__any(bad)) { if ((threadIdx.x & 63) == 0) atomicOr(acc + 1, 1ull); }
+  else if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(acc, (unsigned long long)__double_as_longlong(m));
+}
+__global__ void trd_scale_kernel(const unsigned long long* __restrict__ acc, double* __restrict__ scal) {
+  const double g = __longlong_as_double((long long)acc[0]);
+  const bool nan = acc[1] != 0ull;
+  double f = 1.0;
+  if (g > 0.0 && !nan) {
+    int ex;
+    frexp(g, &ex);
+    f = ldexp(1.0, -ex);               // f * g in [0.5, 1)
   }
+  scal[0] = f;
+  scal[1] = nan ? 1.0 : 0.0;
 }
 
 __global__ void trd_copy_kernel(const double* __restrict__ Ar, const double* __restrict__ Ai, int n, int64_t lda, double* Wr, double* Wi,
@@ -1199,7 +1202,12 @@ inline TrdParams trd_reduce(hipStream_t st, TrdWorkspace& ws, const double* Ar, 
   TrdLayout lay{n, ld, nv, ws.vec.get()};
   TrdParams P = lay.params(ws.W[0].get(), cplx ? ws.W[1].get() : nullptr, keep_reflectors ? ws.V[0].get() : nullptr,
                            (keep_reflectors && cplx) ? ws.V[1].get() : nullptr);
-  hipLaunchKernelGGL(trd_maxdiag_kernel, dim3(1), dim3(256), 0, st, Ar, n, lda, ws.scal.get());
+  {
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(ws.scal.get() + 2);
+    XMCA_HIP(hipMemsetAsync(acc, 0, 2 * sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(trd_maxabs_kernel, dim3(std::min(n, 1024)), dim3(256), 0, st, Ar, Ai, n, lda, acc);
+    hipLaunchKernelGGL(trd_scale_kernel, dim3(1), dim3(1), 0, st, acc, ws.scal.get());
+  }
   hipLaunchKernelGGL(trd_copy_kernel, dim3(n), dim3(256), 0, st, Ar, Ai, n, lda, P.Ar, P.Ai, ld, ws.scal.get());
   ws.resident_used = 0;
 
