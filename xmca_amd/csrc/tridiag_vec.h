@@ -39,6 +39,7 @@ __global__ __launch_bounds__(128) void trd_twisted_kernel(const double* __restri
                                                          const double* __restrict__ lam, double* __restrict__ W, double* __restrict__ Yt,
                                                          int64_t ldy) {
   __shared__ double nrm_sh[2][64];
+  __shared__ int idx_sh[2][64];
   const int lane = threadIdx.x & 63, half = threadIdx.x >> 6;
   const int k = blockIdx.x * 64 + lane;
   const bool live = k < n;
@@ -103,27 +104,35 @@ __global__ __launch_bounds__(128) void trd_twisted_kernel(const double* __restri
   }
   __threadfence_block();
   __syncthreads();
-  // twist index: gamma_i = D+_i + D-_i - (d_i - lambda), smallest |gamma| (both waves scan: no recurrence, pure streaming;
-  // rows past the end repeat row n - 1, which cannot displace the first occurrence of the minimum)
+  // twist index: gamma_i = D+_i + D-_i - (d_i - lambda), smallest |gamma| (no recurrence, pure streaming: each wave scans one
+  // half of the rows, the lower half wins ties - the first occurrence of the minimum, as a single scan would find it; rows
+  // past a half's end repeat its last row, which cannot displace that)
   int r = 0;
   {
+    const int h0s = half == 0 ? 0 : n / 2, h1s = half == 0 ? n / 2 : n;     // (n >= 2: neither half is empty)
     double gbest = 1.7e308;
-    for (int i0 = 0; i0 < n; i0 += B) {
+    r = h0s;
+    for (int i0 = h0s; i0 < h1s; i0 += B) {
       double yp[B], wm[B];
-      const double dv = d[i0 + lane < n ? i0 + lane : n - 1];
+      const double dv = d[i0 + lane < h1s ? i0 + lane : h1s - 1];
 #pragma unroll
       for (int u = 0; u < B; ++u) {
-        const int i = i0 + u < n ? i0 + u : n - 1;
+        const int i = i0 + u < h1s ? i0 + u : h1s - 1;
         yp[u] = Yt[(int64_t)i * ldy + kk];
         wm[u] = W[(int64_t)i * ldy + kk];
       }
 #pragma unroll
       for (int u = 0; u < B; ++u) {
-        const int i = i0 + u < n ? i0 + u : n - 1;
+        const int i = i0 + u < h1s ? i0 + u : h1s - 1;
         const double g = fabs(yp[u] + wm[u] - (trd_lane_value(dv, u) - l));
         if (g < gbest) { gbest = g; r = i; }
       }
     }
+    nrm_sh[half][lane] = gbest;
+    idx_sh[half][lane] = r;
+    __syncthreads();
+    if (nrm_sh[0][lane] <= nrm_sh[1][lane]) r = idx_sh[0][lane];
+    else r = idx_sh[1][lane];
   }
   __syncthreads();                                           // (both waves have read D+ before the upper half overwrites it)
   double nrm = 0.0;
