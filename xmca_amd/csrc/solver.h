@@ -764,7 +764,7 @@ class Solver {
     // Gy[k][l] = h_k h_l / T  sum_s sum_t exp(-2 pi i k s / T) G[s][t] exp(+2 pi i l t / T): a 2-D DFT of G of which the
     // m x m corner is kept (fft.h: T transforms along the rows, m along the columns, each in the LDS of one workgroup) when T
     // factors into 2, 3, 5, 7 and fits; otherwise two products with the explicit Fourier vectors: P1 = G Phi, Gy = D (Phi^H P1) D
-    static const bool fft_on = [] { const char* e = std::getenv("XMCA_FFT"); return !(e && e[0] == '0'); }();
+    constexpr bool fft_on = true;   // (the DFT-by-GEMM form was a run-time switch until round 4)
     FftPlan plan;
     if (fft_on && fft_plan(T, plan)) {
       fft_batch(st, plan, T, G.get(), nullptr, T, 1, +1.0, P1.r(), P1.im.get(), m, 1, m, nullptr, nullptr, 1.0);
@@ -812,7 +812,7 @@ class Solver {
     Bt.ensure((size_t)nv * T, true);
     // Bt[i][t] = sum_k h_k conj(E[i][k]) exp(2 pi i k t / T) / sqrt(T)      (nv x T): nv zero-padded DFTs of length T, or
     // Bt = conj(E D) Phi^T as a product with the explicit Fourier vectors
-    static const bool fft_on = [] { const char* e = std::getenv("XMCA_FFT"); return !(e && e[0] == '0'); }();
+    constexpr bool fft_on = true;   // (the DFT-by-GEMM form was a run-time switch until round 4)
     FftPlan plan;
     if (fft_on && fft_plan(T, plan)) {
       fft_batch(st, plan, nv, Er, Ei, m, 1, +1.0, Bt.r(), Bt.im.get(), T, 1, T, nullptr, nullptr, 1.0 / std::sqrt((double)T), m, true,
