@@ -136,48 +136,56 @@ __global__ __launch_bounds__(128) void trd_twisted_kernel(const double* __restri
   }
   __syncthreads();                                           // (both waves have read D+ before the upper half overwrites it)
   double nrm = 0.0;
+  // The twist index differs from lane to lane, the ROW index of the two vector recurrences must not: with per-lane rows every
+  // load and store of a wave touched 64 different cache lines (round 3-4: 500 of the kernel's 970 us, 16 x the bytes).  Both
+  // loops therefore walk the rows of the whole wave - from the largest twist index down, from the smallest one up - and a lane
+  // joins when the walk reaches its own twist: coalesced rows, e[i] by lane broadcast, the same arithmetic per lane as before.
+  constexpr int B3 = 64;
   if (half == 0) {
-    // upwards from the twist: z(i) = -(e_i / D+_i) z(i+1).  The twist index differs from lane to lane: e[i] is a per-lane
-    // load here, requested with the batch of D+
+    // upwards from the twist: z(i) = -(e_i / D+_i) z(i+1)
     double z = 1.0;
     nrm = 1.0;
     if (live) Yt[(int64_t)r * ldy + k] = 1.0;
-    for (int i0 = r - 1; i0 >= 0; i0 -= B) {
-      double yp[B], eb[B];
+    int rmax = r;
+    for (int o = 32; o > 0; o >>= 1) rmax = max(rmax, __shfl_xor(rmax, o));
+    for (int i0 = rmax - 1; i0 >= 0; i0 -= B3) {
+      double yp[B3];
+      const double ev = e[i0 - lane >= 0 ? i0 - lane : 0];
 #pragma unroll
-      for (int u = 0; u < B; ++u) {
-        const int i = i0 - u >= 0 ? i0 - u : 0;
-        yp[u] = i0 - u >= 0 ? Yt[(int64_t)i * ldy + kk] : 1.0;
-        eb[u] = e[i];
-      }
+      for (int u = 0; u < B3; ++u) yp[u] = Yt[(int64_t)(i0 - u >= 0 ? i0 - u : 0) * ldy + kk];
 #pragma unroll
-      for (int u = 0; u < B; ++u) {
+      for (int u = 0; u < B3; ++u) {
         const int i = i0 - u;
-        if (i >= 0) {
-          z = -(eb[u] * trd_rcp(yp[u])) * z;
-          if (live) Yt[(int64_t)i * ldy + k] = z;
-          nrm += z * z;
+        if (i >= 0) {                                        // (uniform)
+          const double zn = -(trd_lane_value(ev, u) * trd_rcp(yp[u])) * z;
+          if (i < r) {
+            z = zn;
+            if (live) Yt[(int64_t)i * ldy + k] = z;
+            nrm += z * z;
+          }
         }
       }
     }
   } else {
     // downwards: z(i+1) = -(e_i / D-_{i+1}) z(i)
     double z = 1.0;
-    for (int i0 = r; i0 < n - 1; i0 += B) {
-      double wm[B], eb[B];
+    int rmin = r;
+    for (int o = 32; o > 0; o >>= 1) rmin = min(rmin, __shfl_xor(rmin, o));
+    for (int i0 = rmin; i0 < n - 1; i0 += B3) {
+      double wm[B3];
+      const double ev = e[i0 + lane < n - 1 ? i0 + lane : n - 2];
 #pragma unroll
-      for (int u = 0; u < B; ++u) {
-        const int i = i0 + u < n - 1 ? i0 + u : n - 2;
-        wm[u] = i0 + u < n - 1 ? W[(int64_t)(i + 1) * ldy + kk] : 1.0;
-        eb[u] = e[i];
-      }
+      for (int u = 0; u < B3; ++u) wm[u] = W[(int64_t)((i0 + u < n - 1 ? i0 + u : n - 2) + 1) * ldy + kk];
 #pragma unroll
-      for (int u = 0; u < B; ++u) {
+      for (int u = 0; u < B3; ++u) {
         const int i = i0 + u;
-        if (i < n - 1) {
-          z = -(eb[u] * trd_rcp(wm[u])) * z;
-          if (live) Yt[(int64_t)(i + 1) * ldy + k] = z;
-          nrm += z * z;
+        if (i < n - 1) {                                     // (uniform)
+          const double zn = -(trd_lane_value(ev, u) * trd_rcp(wm[u])) * z;
+          if (i >= r) {
+            z = zn;
+            if (live) Yt[(int64_t)(i + 1) * ldy + k] = z;
+            nrm += z * z;
+          }
         }
       }
     }
@@ -187,12 +195,12 @@ __global__ __launch_bounds__(128) void trd_twisted_kernel(const double* __restri
   __syncthreads();
   const double s = 1.0 / sqrt(nrm_sh[0][lane] + nrm_sh[1][lane]);
   const int h0 = half == 0 ? 0 : n / 2, h1 = half == 0 ? n / 2 : n;
-  for (int i0 = h0; i0 < h1; i0 += B) {
-    double y[B];
+  for (int i0 = h0; i0 < h1; i0 += B3) {
+    double y[B3];
 #pragma unroll
-    for (int u = 0; u < B; ++u) y[u] = i0 + u < h1 ? Yt[(int64_t)(i0 + u) * ldy + kk] : 0.0;
+    for (int u = 0; u < B3; ++u) y[u] = Yt[(int64_t)(i0 + u < h1 ? i0 + u : h1 - 1) * ldy + kk];
 #pragma unroll
-    for (int u = 0; u < B; ++u)
+    for (int u = 0; u < B3; ++u)
       if (live && i0 + u < h1) Yt[(int64_t)(i0 + u) * ldy + k] = y[u] * s;
   }
 }
