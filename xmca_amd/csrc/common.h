@@ -250,6 +250,16 @@ inline PersistGate& persist_gate() {   // of the calling thread's current device
   return *g;
 }
 
+// true on a host thread that runs one of SEVERAL surrogate lanes (rule_n / bootstrapping: xmca_hip.cpp run_lanes).  Lanes keep
+// to one stream each: with a second stream per lane (the eigensolver's compact-WY factors, tridiag_vec.h) the persistent
+// reductions of four lanes ran out of their bounded spins now and then (measured: give-ups in 2 of 6 processes of the gate
+// test against 0 of 6 - eight streams of one process on one device, plus the exclusive grids, is more than its hardware queues
+// take without time-slicing).
+inline bool& in_surrogate_lanes() {
+  thread_local bool v = false;
+  return v;
+}
+
 // XMCA_TRACE=jacobi,solve,rot (any subset, or "all"): progress lines of the eigensolver sweeps / the solver's route and
 // consistency decisions / the rotation loop on stderr.  One switch instead of three.
 static inline bool xmca_trace(const char* what) {

@@ -58,15 +58,26 @@ __device__ __forceinline__ void fft_stage(const double* __restrict__ ar, const d
     const int k = j % Ns;
     const double ang = 2.0 * (double)k / (double)(Ns * R);     // in units of pi
     double vr[R], vi[R];
+    // twiddles w^r, w = exp(sign i pi ang): ONE sincospi per butterfly and R - 2 complex products (round 4: a sincospi per r
+    // - a hundred double-precision instructions each - was most of the kernel's time at one wave per SIMD); none in the first
+    // stage, where w = 1
+    double c1 = 1.0, s1 = 0.0;
+    if (Ns > 1) {
+      sincospi(ang, &s1, &c1);
+      s1 *= sign;
+    }
+    double wr = c1, wi = s1;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const double xr = ar[j + r * nr], xi = ai[j + r * nr];
       if (r == 0) { vr[0] = xr; vi[0] = xi; continue; }
-      double sn, cs;
-      sincospi(ang * (double)r, &sn, &cs);
-      sn *= sign;
-      vr[r] = xr * cs - xi * sn;
-      vi[r] = xr * sn + xi * cs;
+      vr[r] = xr * wr - xi * wi;
+      vi[r] = xr * wi + xi * wr;
+      if (r + 1 < R) {
+        const double t = wr * c1 - wi * s1;
+        wi = wr * s1 + wi * c1;
+        wr = t;
+      }
     }
     const int j0 = (j - k) * R + k;
 #pragma unroll

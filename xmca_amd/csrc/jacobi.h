@@ -163,6 +163,7 @@ inline void hermitian_evd(hipStream_t st, EvdWorkspace& ws, const double* Ar, co
   // (repeated eigenvalues, null spaces of dimension > 1) come back here and take the Jacobi sweeps below.
   const int trd_vec_min_n = [] { const char* e = std::getenv("XMCA_TRIDIAG_VEC_MIN_N"); return e ? std::atoi(e) : 768; }();
   if (Zr && !nearly_diagonal && trd_enabled() && n >= trd_vec_min_n && trd_fits(n, Ai != nullptr)) {
+    ws.trdv.count_call();
     TrdParams P = trd_reduce(st, ws.trd, Ar, Ai, n, lda, true);
     trd_wy_prepare(st, ws.trdv, ws.gws, P, Ai != nullptr);  // (from the second call on: on a second stream, under the two kernels below)
     std::vector<double> lam_t;

@@ -406,6 +406,16 @@ struct TrdVecWorkspace {
   GemmWorkspace side_gws;
   bool prepared = false, joined = true;
   int calls = 0;
+  // Called once per eigen-decomposition with vectors, BEFORE the reduction is queued.  The second stream is made on the second
+  // call - and with every CU of the device claimed at the gate of the persistent kernels: creating a stream (a hardware queue)
+  // while a persistent grid of another surrogate lane is in flight stalled that grid long enough for its bounded spins to run
+  // out (a give-up and a repeated reduction in the first rotated rule_n call after the warm-up, four lanes).
+  void count_call() {
+    if (side || in_surrogate_lanes() || ++calls < 2) return;      // (lanes keep to one stream each: common.h)
+    PersistGate& gate = persist_gate();
+    PersistGate::Claim alone(gate, gate.n_cus);
+    side_init();
+  }
   void side_init() {
     if (side) return;
     XMCA_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
@@ -442,9 +452,8 @@ inline void trd_wy_prepare(hipStream_t st, TrdVecWorkspace& vw, GemmWorkspace& g
   if (vw.plan.n != n) vw.plan.build(st, n);
   // Creating a stream costs ~10 ms (measured: hipStreamCreateWithFlags inside the first solve of a process) - thirty solves'
   // worth of what the overlap saves.  The first call of a workspace therefore stays on `st`; from the second call on the
-  // workspace belongs to somebody who solves repeatedly, and the second stream is made.
-  const bool use_side = vw.side != nullptr || ++vw.calls >= 2;
-  if (use_side) vw.side_init();
+  // workspace belongs to somebody who solves repeatedly, and the second stream exists (count_call).
+  const bool use_side = vw.side != nullptr && !in_surrogate_lanes();   // (made by TrdVecWorkspace::count_call, in front of the reduction)
   // Everything the second stream touches is allocated OUTSIDE the handle's pool: a pool hands a released block to the next
   // taker on the strength of stream order, which holds for one stream only (a split-K workspace that grows between two GEMMs
   // of this function would otherwise go back to the pool - and to a kernel on `st` - while the first GEMM still writes it).

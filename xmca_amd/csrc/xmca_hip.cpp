@@ -560,6 +560,11 @@ void run_lanes(xmca_handle* h, int lanes, F&& lane_body) {
       ::xmca::PoolScope scope(&lh->pool);
       XMCA_HIP(hipSetDevice(h->device));
       lh->tm.enabled = h->tm.enabled;
+      struct LaneFlag {
+        bool prev;
+        explicit LaneFlag(bool on) : prev(::xmca::in_surrogate_lanes()) { ::xmca::in_surrogate_lanes() = on; }
+        ~LaneFlag() { ::xmca::in_surrogate_lanes() = prev; }
+      } flag(lanes > 1);
       lane_body(lh, j);
       XMCA_HIP(hipStreamSynchronize(lh->st));
     } catch (...) {
