@@ -298,23 +298,6 @@ __global__ __launch_bounds__(64) void trd_wy_tinv_kernel(const double* __restric
   }
 }
 
-// dst[c][r] = src[r][c] for an n x n plane (64 x 64 tiles through LDS)
-__global__ __launch_bounds__(256) void trd_transpose_kernel(const double* __restrict__ src, int64_t lds_, double* __restrict__ dst, int64_t ldd,
-                                                            int n) {
-  __shared__ double t[64][65];
-  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  for (int rr = ty; rr < 64; rr += 4) {
-    const int r = r0 + rr, c = c0 + tx;
-    t[rr][tx] = (r < n && c < n) ? src[(int64_t)r * lds_ + c] : 0.0;
-  }
-  __syncthreads();
-  for (int cc = ty; cc < 64; cc += 4) {
-    const int c = c0 + cc, r = r0 + tx;
-    if (c < n && r < n) dst[(int64_t)c * ldd + r] = t[tx][cc];
-  }
-}
-
 // out[0] = max |S - I| (as the bit pattern of a non-negative double, atomicMax), NaN -> +inf
 __global__ void trd_orth_kernel(const double* __restrict__ Sr, const double* __restrict__ Si, int n, int64_t ld, unsigned long long* out) {
   double m = 0.0;
@@ -566,12 +549,9 @@ inline bool trd_eigenvectors(hipStream_t st, TrdWorkspace& ws, TrdVecWorkspace& 
     if (last) {
       // out = (3/2 I - 1/2 S)[rows reversed] Z^H :  out[kk][i] = conj(u_{n-1-kk}[i])
       hipLaunchKernelGGL(trd_ns_matrix_kernel, dim3(n), dim3(256), 0, st, Sr, Si, n, ld, 1, Wr, Wi);
-      // (through the transposed vectors: the general GEMM kernel runs the k-fast x n-fast orientation at twice the rate of
-      //  the k-fast x k-fast one; the transposition is a 0.05 ms pass)
-      const dim3 tg((unsigned)ceil_div(n, 64), (unsigned)ceil_div(n, 64));
-      hipLaunchKernelGGL(trd_transpose_kernel, tg, dim3(256), 0, st, Yr, ld, Sr, ld, n);
-      if (cplx) hipLaunchKernelGGL(trd_transpose_kernel, tg, dim3(256), 0, st, Yi, ld, Si, ld, n);
-      cgemm<double>(st, gws, Wr, Wi, ld, true, false, Sr, Si, ld, true, true, Zr, Zi, ldz, n, n, n, 1.0, nullptr, nullptr, false);
+      // (B(k, n = i) = conj(Z[i][k]): the vectors as they lie, contraction index fast - the round-4 GEMM runs every
+      //  orientation at the same rate; rounds 2-3 went through a transposed copy)
+      cgemm<double>(st, gws, Wr, Wi, ld, true, false, Yr, Yi, ld, false, true, Zr, Zi, ldz, n, n, n, 1.0, nullptr, nullptr, false);
       ++vw.ns_steps;
       XMCA_HIP(hipGetLastError());
       return true;
