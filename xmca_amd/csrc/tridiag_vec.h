@@ -538,6 +538,14 @@ inline bool trd_eigenvectors(hipStream_t st, TrdWorkspace& ws, TrdVecWorkspace& 
     cgemm<double>(st, gws, Yr, Yi, ld, false, true, Yr, Yi, ld, true, false, Sr, Si, ld, n, n, n, 1.0, nullptr, nullptr, true);
     XMCA_HIP(hipMemsetAsync(vw.orth.get(), 0, sizeof(unsigned long long) * 2, st));
     hipLaunchKernelGGL(trd_orth_kernel, dim3(std::min(n, 1024)), dim3(256), 0, st, Sr, Si, n, ld, vw.orth.get());
+    // The common case - max |S - I| <= 1e-6, one more step leaves its square - is queued BEFORE the host learns the number:
+    // out = (3/2 I - 1/2 S)[rows reversed] Z^H :  out[kk][i] = conj(u_{n-1-kk}[i]), with B(k, n = i) = conj(Z[i][k]), the
+    // vectors as they lie (the round-4 GEMM runs every orientation at the same rate; rounds 2-3 went through a transposed
+    // copy).  One host round trip per call instead of two; a spectrum that needs a second step (or the Jacobi sweeps) pays
+    // for a product whose result is overwritten.
+    hipLaunchKernelGGL(trd_ns_matrix_kernel, dim3(n), dim3(256), 0, st, Sr, Si, n, ld, 1, Wr, Wi);
+    cgemm<double>(st, gws, Wr, Wi, ld, true, false, Yr, Yi, ld, false, true, Zr, Zi, ldz, n, n, n, 1.0, nullptr, nullptr, false);
+    XMCA_HIP(hipGetLastError());
     unsigned long long bits = 0;
     XMCA_HIP(hipMemcpyAsync(&bits, vw.orth.get(), sizeof(bits), hipMemcpyDeviceToHost, st));
     XMCA_HIP(hipStreamSynchronize(st));
@@ -545,15 +553,8 @@ inline bool trd_eigenvectors(hipStream_t st, TrdWorkspace& ws, TrdVecWorkspace& 
     std::memcpy(&off, &bits, sizeof(off));
     if (round == 0) vw.last_orth = off;
     if (!(off <= 0.3)) return false;                          // clusters (or NaN): not repairable by Newton-Schulz
-    const bool last = off <= 1e-6;                            // one more step leaves off^2 ~ 1e-12 or less
-    if (last) {
-      // out = (3/2 I - 1/2 S)[rows reversed] Z^H :  out[kk][i] = conj(u_{n-1-kk}[i])
-      hipLaunchKernelGGL(trd_ns_matrix_kernel, dim3(n), dim3(256), 0, st, Sr, Si, n, ld, 1, Wr, Wi);
-      // (B(k, n = i) = conj(Z[i][k]): the vectors as they lie, contraction index fast - the round-4 GEMM runs every
-      //  orientation at the same rate; rounds 2-3 went through a transposed copy)
-      cgemm<double>(st, gws, Wr, Wi, ld, true, false, Yr, Yi, ld, false, true, Zr, Zi, ldz, n, n, n, 1.0, nullptr, nullptr, false);
+    if (off <= 1e-6) {                                        // the step queued above was the last one
       ++vw.ns_steps;
-      XMCA_HIP(hipGetLastError());
       return true;
     }
     // Z <- Z (3/2 I - 1/2 S)
