@@ -110,10 +110,28 @@ __global__ __launch_bounds__(256) void fft_batch_kernel(const double* __restrict
   double* br = ai + n;
   double* bi = br + n;
   const int64_t b = blockIdx.x;
-  for (int t = threadIdx.x; t < n; t += blockDim.x) {
-    const double f = t < n_in ? (sin_ ? sin_[t] : 1.0) : 0.0;
-    ar[t] = t < n_in ? f * in_r[b * in_bs + t * in_es] : 0.0;
-    ai[t] = (t < n_in && in_i) ? (conj_in ? -f : f) * in_i[b * in_bs + t * in_es] : 0.0;
+  // (eight elements per thread requested before the first one is stored: with one wave per SIMD - a transform of 5000 points
+  //  takes the whole LDS of a CU - a load per loop iteration left the memory pipe idle for most of the 14 us this took)
+  for (int t0 = threadIdx.x; t0 < n; t0 += 8 * (int)blockDim.x) {
+    double xr[8], xi[8], fs[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int t = t0 + u * (int)blockDim.x;
+      const bool in = t < n_in;
+      const int tc = in ? t : 0;
+      fs[u] = (in && sin_) ? sin_[tc] : 1.0;
+      xr[u] = in_r[b * in_bs + tc * in_es];
+      xi[u] = in_i ? in_i[b * in_bs + tc * in_es] : 0.0;
+      if (!in) { xr[u] = 0.0; xi[u] = 0.0; }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int t = t0 + u * (int)blockDim.x;
+      if (t < n) {
+        ar[t] = fs[u] * xr[u];
+        ai[t] = (conj_in ? -fs[u] : fs[u]) * xi[u];
+      }
+    }
   }
   __syncthreads();
   int Ns = 1;
@@ -132,10 +150,21 @@ __global__ __launch_bounds__(256) void fft_batch_kernel(const double* __restrict
     { double* t = ai; ai = bi; bi = t; }
   }
   const double fb = scale * (sb ? sb[b] : 1.0);
-  for (int k = threadIdx.x; k < n_keep; k += blockDim.x) {
-    const double f = fb * (sa ? sa[k] : 1.0);
-    out_r[b * out_bs + k * out_es] = ar[k] * f;
-    out_i[b * out_bs + k * out_es] = ai[k] * f;
+  for (int k0 = threadIdx.x; k0 < n_keep; k0 += 4 * (int)blockDim.x) {
+    double fk[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + u * (int)blockDim.x;
+      fk[u] = fb * ((sa && k < n_keep) ? sa[k] : 1.0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + u * (int)blockDim.x;
+      if (k < n_keep) {
+        out_r[b * out_bs + k * out_es] = ar[k] * fk[u];
+        out_i[b * out_bs + k * out_es] = ai[k] * fk[u];
+      }
+    }
   }
 }
 
