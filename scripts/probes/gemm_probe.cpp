@@ -161,6 +161,12 @@ int main(int argc, char** argv) {
         bad += check_case<float>(st, ws, 390, 390, 3000, akf, 0, true, 4, 0, false, 1.0, 0.0, false);
       }
       printf("%s\n", bad ? "FAILURES" : "all ok");
+    } else if (!strcmp(mode, "shape")) {      // shape M N K akf bnf upper splits reps [f32]
+      const int M = atoi(argv[2]), N = atoi(argv[3]), K = atoi(argv[4]), akf = atoi(argv[5]), bnf = atoi(argv[6]), up = atoi(argv[7]);
+      const int sp = atoi(argv[8]), reps = atoi(argv[9]);
+      const double fl = up ? (double)M * (M + 1) * K : 2.0 * M * N * K;
+      if (argc > 10) bench_case<float>(st, ws, "shape", M, N, K, akf, bnf, up, sp, reps, fl);
+      else bench_case<double>(st, ws, "shape", M, N, K, akf, bnf, up, sp, reps, fl);
     } else if (!strcmp(mode, "sweep")) {
       const int reps = argc > 2 ? atoi(argv[2]) : 5;
       const Shape shapes[] = {
