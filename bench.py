@@ -472,6 +472,10 @@ def main():
                              "surrogates_per_s_full_size": 1.0 / (64.0 * dtq)}
 
     if rank == 0:
+        try:        # persistent launches of this process that ran out of their bounded spins and were repeated (0 on a GPU of its own)
+            extra["persistent_giveups"] = int(_hip.load_library().xmca_persistent_giveups())
+        except Exception:                                         # noqa: BLE001
+            pass
         line = {
             "metric": "MCA solve+rotate throughput (ms_per_step = solve+rotate wall-clock, ms); rule_n surrogates/s in `rule_n`",
             "value": value, "unit": "solve+rotate/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
