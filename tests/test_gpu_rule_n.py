@@ -365,6 +365,34 @@ def test_persistent_kernels_of_four_lanes_pass_one_gate():
     assert out["seconds"] < 16 * 0.05                                  # ~15 ms of kernels per surrogate; one give-up alone costs 0.2 s
 
 
+def test_dead_workgroups_of_the_tagged_reduction_do_not_stall_two_lanes():
+    """Two surrogates in flight at a size whose persistent reduction has many more workgroups than live rows towards its end
+    (m = 451 complex, 113 workgroups; m = 900 real).  In the tagged exchange a workgroup without live rows publishes nothing,
+    so nobody waits for it; as long as it kept listening it could fall two columns behind (the other lane's kernels on its CU),
+    find its slots overwritten with the tag of the column after next, run out of its spins and force the reduction to be
+    repeated launch by launch: a give-up in nearly every call at this size, 0.2 s each, and - through the different summation
+    order of the fallback - different bits from call to call.  Dead workgroups leave now, and the writer of d / e / tau is the
+    owner of the last row: no give-up, the same bits in every call."""
+    import subprocess
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r); from xmca_amd import _hip; h = _hip.Handle(0); lib = _hip.load_library();"
+            "out = {};\n"
+            "for T, Nx, Ny, c in ((900, 2200, 1700, True), (900, 2200, 1700, False)):\n"
+            "    args = (T, Nx, Ny, 2, c, False, 0, 0, 1e-8)\n"
+            "    ref, _ = h.rule_n(*args, 0, 8, 3, np.float64, T)\n"
+            "    g0 = lib.xmca_persistent_giveups(); same = True\n"
+            "    for r in range(5):\n"
+            "        sp, _ = h.rule_n(*args, 0, 8, 3, np.float64, T); same = same and bool(np.array_equal(sp, ref))\n"
+            "    out[str(c)] = [int(lib.xmca_persistent_giveups() - g0), same, h.timings().get('trd_resident_calls', 0)]\n"
+            "print(json.dumps(out))" % REPO)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, XMCA_RULE_N_LANES="2", XMCA_TRACE="giveup"), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    for key in ("True", "False"):
+        assert out[key][0] == 0 and out[key][1] is True and out[key][2] > 0, (out, r.stderr[-600:])
+
+
 def test_rule_n_spectra_do_not_depend_on_the_number_of_lanes():
     """xmca_rule_n keeps several surrogates in flight (one stream + workspaces + host thread per lane, xmca_hip.cpp
     rule_n_impl); the generator is keyed by (seed, run, side), so 1, 2, 3 and 5 lanes must give the same bits - unrotated,

@@ -463,6 +463,19 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nwg = (int)gridDim.x, NW = nwg * (TRD_RES_THREADS / 64), g = (int)blockIdx.x * (TRD_RES_THREADS / 64) + wave;
+  // The workgroup that writes d, e, tau and the reflectors is the owner of the LAST row: it publishes something in every column, so
+  // everybody waits for it and nobody can run ahead of it.  (Until round 4 this was workgroup 0, whose rows are the first to
+  // die: from then on it only listened - and a listener is not flow-controlled in the tagged exchange, see the column loop.)
+  const int writer = ((n - 1 - first_res) % NW) / (TRD_RES_THREADS / 64);
+  const bool is_writer = (int)blockIdx.x == writer;
+  // last row of this workgroup: the largest resident row below n, else its last streamed row, else none
+  int wg_last = -1;
+  {
+    const int b4 = (int)blockIdx.x * (TRD_RES_THREADS / 64);
+    for (int t = RR - 1; t >= 0 && wg_last < 0; --t)
+      if (first_res + b4 + NW * t < n) wg_last = min(first_res + b4 + NW * t + TRD_RES_THREADS / 64 - 1, n - 1);
+    if (wg_last < 0 && first_res - 1 >= (int)blockIdx.x) wg_last = ((first_res - 1 - (int)blockIdx.x) / nwg) * nwg + (int)blockIdx.x;
+  }
   double* bV[2] = {trd_lds, trd_lds + 3 * LV};                       // v_{j-1}   (re, im)
   double* bW[2] = {trd_lds + LV, trd_lds + 4 * LV};                  // w_{j-1}
   double* bX[2] = {trd_lds + 2 * LV, trd_lds + 5 * LV};              // column j -> v_j
@@ -498,8 +511,14 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
   double tpr = 0.0, tpi = 0.0;                     // tau of the previous column
   __syncthreads();
 
-  const bool prof = P.prof && blockIdx.x == 0 && tid == 0;
+  const bool prof = P.prof && is_writer && tid == 0;
   for (int j = 0; j < n; ++j) {
+    // Tagged exchange: a workgroup whose rows are all dead has nothing left to publish - so nobody waits for it - and nothing
+    // to update: it leaves.  Staying on as a listener was a hazard: it is not flow-controlled, and once it fell two columns
+    // behind (a second surrogate lane's kernels on its CU are enough) the live workgroups had overwritten the slots it was
+    // still waiting for with the tag of the column after next - its spins ran out, the whole reduction was repeated launch by
+    // launch (0.2 s; with two lanes at n = 451 complex in nearly every call, at n = 2000 in one of thirty).
+    if (TAG && !is_writer && wg_last <= j) break;
     const int prev = (j + 1) & 1, cur = j & 1;
     const int m = n - j - 1;
     if (prof) P.prof[8 * j + 0] = __builtin_amdgcn_s_memtime();
@@ -557,7 +576,10 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
             }
           }
           if (__all(all)) break;
-          if (++spins > (1u << 20)) { give_up_sh = 1; break; }       // (~1.5 s) a workgroup is missing: report, never hang.  All persistent launches of THIS process pass one gate (common.h), so only a foreign process can cause it; 0.2 s (round 3) was less than the first launch on a cold device can take
+          if (++spins > (1u << 20)) {
+            if (tid == 0 && atomicCAS(S.give_up + 1, 0, 1) == 0) { S.give_up[2] = j; S.give_up[3] = (int)blockIdx.x; }   // (XMCA_TRACE=giveup)
+            give_up_sh = 1; break;
+          }       // (~1.5 s) a workgroup is missing: report, never hang.  All persistent launches of THIS process pass one gate (common.h), so only a foreign process can cause it; 0.2 s (round 3) was less than the first launch on a cold device can take
           __builtin_amdgcn_s_sleep(1);
         }
       }
@@ -644,7 +666,7 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
     xn2 = trd_block_sum_n<TRD_RES_THREADS / 64>(xn2, red);
     if (prof) P.prof[8 * j + 2] = __builtin_amdgcn_s_memtime();
     if (m == 0) {
-      if (blockIdx.x == 0 && tid == 0) P.d[j] = dj_sh;
+      if (is_writer && tid == 0) P.d[j] = dj_sh;
       break;
     }
     const double a0r = bX[0][j + 1], a0i = CPLX ? bX[1][j + 1] : 0.0;
@@ -679,14 +701,14 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
         }
         bX[0][k] = vr;
         if (CPLX) bX[1][k] = vi;
-        if (blockIdx.x == 0 && P.Vr) {               // (tau = 0: H_j = I - the stored reflector is the zero vector)
+        if (is_writer && P.Vr) {               // (tau = 0: H_j = I - the stored reflector is the zero vector)
           const bool live = tr != 0.0 || ti != 0.0;
           P.Vr[(int64_t)j * P.ld + k] = live ? vr : 0.0;
           if (CPLX) P.Vi[(int64_t)j * P.ld + k] = live ? vi : 0.0;
         }
       }
     }
-    if (blockIdx.x == 0 && tid == 0) {
+    if (is_writer && tid == 0) {
       P.d[j] = dj_sh;
       P.e[j] = beta;
       P.tau[0][j] = tr;
@@ -1270,8 +1292,12 @@ inline TrdParams trd_reduce(hipStream_t st, TrdWorkspace& ws, const double* Ar, 
       hipLaunchKernelGGL(fn, dim3(wgs), dim3(TRD_RES_THREADS), lds, st, P, S, first_res);
       ws.ev_end(st);
       XMCA_HIP(hipGetLastError());
-      XMCA_HIP(hipMemcpyAsync(&gave_up, S.give_up, sizeof(int), hipMemcpyDeviceToHost, st));
+      int dbg[4] = {0};
+      XMCA_HIP(hipMemcpyAsync(dbg, S.give_up, sizeof(dbg), hipMemcpyDeviceToHost, st));
       XMCA_HIP(hipStreamSynchronize(st));
+      gave_up = dbg[0];
+      if (gave_up && xmca_trace("giveup"))
+        std::fprintf(stderr, "xmca: trd_resident_kernel: workgroup %d of %d ran out of its spins at column %d of %d\n", dbg[3], wgs, dbg[2], n);
     }
     if (prof_file_r) {
       std::vector<unsigned long long> hp((size_t)8 * n);
