@@ -349,7 +349,7 @@ def main():
     if not args.no_rule_n:
         Tn, Nxn, Nyn = 5000, 20000, 15000               # BASELINE.json configs[3]: rule_n on the synthetic MCA config
         model = rule_n_model(MCA, h, Tn, Nxn, Nyn)
-        model.rule_n(2 * world, seed=7)               # two untimed surrogates per rank (workspaces of both lanes, tile maps)
+        model.rule_n(3 * world, seed=7)               # three untimed surrogates per rank (workspaces of every lane, tile maps)
         n_runs = args.rule_n_runs * world
         barrier()
         t0 = time.perf_counter()
@@ -360,7 +360,7 @@ def main():
             tt = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
             td.all_reduce(tt, op=td.ReduceOp.MAX)
             dt = float(tt.item())
-        lanes = int(os.environ.get("XMCA_RULE_N_LANES", "2"))
+        lanes = int(os.environ.get("XMCA_RULE_N_LANES", "3"))
         extra["rule_n"] = {"config": "C4: MCA T=%d x (%d, %d) f64 surrogates, complexify=True, unrotated; %d runs per GPU, "
                                      "run-sharded, one all_gather (%s); %d surrogates in flight per GPU (XMCA_RULE_N_LANES)" % (
                                          Tn, Nxn, Nyn, args.rule_n_runs, backend if world > 1 else "single rank", lanes),

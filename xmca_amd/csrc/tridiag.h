@@ -425,6 +425,7 @@ struct TrdSync {
   int* give_up;
   int poll_delay;         // 64-cycle units to sleep before the first poll (polling early only disturbs the publishers)
   int tag_delay;          // tagged exchange: 64-cycle units to sleep before the loads of a column are requested
+  int contiguous;         // rows of a wave: first_res + RR g + t (its RR rows adjacent) instead of first_res + g + NW t (strided)
 };
 
 
@@ -466,14 +467,27 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
   // The workgroup that writes d, e, tau and the reflectors is the owner of the LAST row: it publishes something in every column, so
   // everybody waits for it and nobody can run ahead of it.  (Until round 4 this was workgroup 0, whose rows are the first to
   // die: from then on it only listened - and a listener is not flow-controlled in the tagged exchange, see the column loop.)
-  const int writer = ((n - 1 - first_res) % NW) / (TRD_RES_THREADS / 64);
+  // Row t of wave g: first_res + RG g + RT t.  Strided (RG = 1, RT = NW: every wave holds a row of every stripe - the pass
+  // shrinks as the stripes die, the workgroups leave during the last stripe only) or contiguous (RG = RR, RT = 1: the RR rows of
+  // a wave are adjacent, a workgroup owns 4 RR consecutive rows and leaves - frees its CU for the kernels of another surrogate
+  // lane - when they are dead, from early on; the pass keeps its full length).  The arithmetic of a row does not depend on
+  // who owns it: both forms give the same bits.
+  const int RG = S.contiguous ? RR : 1, RT = S.contiguous ? 1 : NW;
+  int rowi[RR];                                    // the wave's rows (scalars: computed once, not per use inside the column loop)
+#pragma unroll
+  for (int t = 0; t < RR; ++t) rowi[t] = __builtin_amdgcn_readfirstlane(first_res + g * RG + RT * t);
+  const int g_last = S.contiguous ? (n - 1 - first_res) / RR : (n - 1 - first_res) % NW;
+  const int writer = g_last / (TRD_RES_THREADS / 64);
   const bool is_writer = (int)blockIdx.x == writer;
   // last row of this workgroup: the largest resident row below n, else its last streamed row, else none
   int wg_last = -1;
   {
     const int b4 = (int)blockIdx.x * (TRD_RES_THREADS / 64);
-    for (int t = RR - 1; t >= 0 && wg_last < 0; --t)
-      if (first_res + b4 + NW * t < n) wg_last = min(first_res + b4 + NW * t + TRD_RES_THREADS / 64 - 1, n - 1);
+    for (int t = RR - 1; t >= 0; --t)
+      for (int w = TRD_RES_THREADS / 64 - 1; w >= 0; --w) {
+        const int i = first_res + (b4 + w) * RG + RT * t;
+        if (i < n) wg_last = max(wg_last, i);
+      }
     if (wg_last < 0 && first_res - 1 >= (int)blockIdx.x) wg_last = ((first_res - 1 - (int)blockIdx.x) / nwg) * nwg + (int)blockIdx.x;
   }
   double* bV[2] = {trd_lds, trd_lds + 3 * LV};                       // v_{j-1}   (re, im)
@@ -492,7 +506,7 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
   double2 ar[RR][NC], ai[RR][NC];
 #pragma unroll
   for (int t = 0; t < RR; ++t) {
-    const int i = first_res + g + NW * t;
+    const int i = rowi[t];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       ar[t][c] = make_double2(0.0, 0.0);
@@ -823,11 +837,11 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
         }
       }
     }
-    if (first_res + g + NW * (RR - 1) > j) {        // (uniform) the wave still owns a live resident row
+    if (rowi[RR - 1] > j) {        // (uniform) the wave still owns a live resident row
       double vpr[RR], vpi[RR], wpr[RR], wpi[RR], accr[RR], acci[RR];
 #pragma unroll
       for (int t = 0; t < RR; ++t) {
-        const int i = first_res + g + NW * t;
+        const int i = rowi[t];
         const int ii = i < n ? i : 0;                // (bV[0] = bW[0] = 0 from column 1 on, and the registers of such a row are 0)
         vpr[t] = i < n ? bV[0][ii] : 0.0; wpr[t] = i < n ? bW[0][ii] : 0.0;
         vpi[t] = (CPLX && i < n) ? bV[1][ii] : 0.0; wpi[t] = (CPLX && i < n) ? bW[1][ii] : 0.0;
@@ -881,7 +895,7 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
       // the consumers
 #pragma unroll
       for (int t = 0; t < RR; ++t) {
-        if (first_res + g + NW * t == j + 1) {             // wave-uniform
+        if (rowi[t] == j + 1) {             // wave-uniform
           // (the lane offset goes through an empty asm: the NC store offsets 128 c + 2 lane are loop invariants, and hipcc
           // hoists them out of the COLUMN loop into registers of their own - 18 to 32 of them next to the resident rows,
           // which is what pushed the tagged complex NC = 20 build into scratch in round 3)
@@ -903,7 +917,7 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
       }
 #pragma unroll
       for (int t = 0; t < RR; ++t) {
-        const int i = first_res + g + NW * t;
+        const int i = rowi[t];
         if (i < n && i > j) {                              // wave-uniform
           const double yr = trd_wave_sum_dpp(accr[t]);
           const double yi = CPLX ? trd_wave_sum_dpp(acci[t]) : 0.0;
@@ -1254,6 +1268,7 @@ inline TrdParams trd_reduce(hipStream_t st, TrdWorkspace& ws, const double* Ar, 
     for (int a = 0; a < 2; ++a) for (int c = 0; c < 2; ++c) { S.rowbuf[a][c] = q; q += lv; }
     S.flags = ws.flags.get();
     S.poll_delay = 16;      // (flags form; swept 8...48 in round 3: flat)
+    S.contiguous = in_surrogate_lanes() ? 1 : 0;   // (several surrogates in flight: workgroups that leave early feed the other lanes)
     S.tag_delay = 24;       // swept 0...48 in rounds 3 and 4: flat optimum 20-28, real and complex   // (real: 0 -> 23.4 ms at n = 2920, 4.77 at 1000; 24 -> 22.4, 3.72)
     // column 0 reads its row like every other column: from rowbuf (parity 0)
     // (the tagged form reads row 0 from the working copy: the exchange buffers must start as zeros)

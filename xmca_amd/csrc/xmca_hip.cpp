@@ -508,7 +508,7 @@ struct ReplicateRunner {
 // second surrogate's kernels fill that: measured at C4 as two PROCESSES sharing the GPU +34 % surrogates/s
 // (profiles/r02_bench_shared_gpu_2ranks.json), now inside one process.  Lane j takes the runs j, j + lanes, ...; the
 // generator is keyed by (seed, run, side), so the spectra do not depend on the number of lanes.  XMCA_RULE_N_LANES
-// (default: 2 for eigenproblems of 2000 and more, 4 below; 1 = the plain loop).
+// (default: 3 for eigenproblems of 2000 and more, 4 below; 1 = the plain loop).
 template <typename TI>
 void rule_n_lane(xmca_handle* h, int64_t T, int64_t Nx, int64_t Ny, int n_fields, const double* ht_host, int rotated, int p, int power,
                  double tol, int64_t run_begin, int64_t run_end, int64_t first, int64_t stride, uint64_t seed, double* spectra, int* kept,
@@ -539,7 +539,9 @@ static int lanes_for(int64_t eig_n, int64_t n_runs) {
   // measured on MI355X (scripts/rule_n_bench.py, surrogates/s with 1 / 2 / 3 / 4 lanes): C4 8.0 / 10.6 / 10.4 / 10.4,
   // C2-shaped EOF 25.8 / 32.9 / 33.1 / 32.3, C1-shaped (eigenproblems of 675) 109 / 191 / 265 / 337
   static const int lanes_env = [] { const char* e = std::getenv("XMCA_RULE_N_LANES"); return e ? std::max(1, std::min(8, std::atoi(e))) : 0; }();
-  const int lanes_wanted = lanes_env ? lanes_env : (eig_n >= 2000 ? 2 : 4);
+  // (round 4, contiguous row ownership in the persistent reduction - its workgroups leave from early on: C4 with 2 / 3 / 4 / 5
+  //  lanes 48.2 / 45.9 / 45.9 / 47.0 ms per surrogate; C2-shaped EOF and the rotated cases do not care)
+  const int lanes_wanted = lanes_env ? lanes_env : (eig_n >= 2000 ? 3 : 4);
   return (int)std::min<int64_t>(lanes_wanted, std::max<int64_t>(n_runs, 1));
 }
 
