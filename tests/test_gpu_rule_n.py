@@ -362,7 +362,7 @@ def test_persistent_kernels_of_four_lanes_pass_one_gate():
     assert out["giveups"] == 0, r.stderr[-1000:]
     assert out["kept"] >= 12                                           # (a white-noise surrogate may not converge in 1000 iterations: dropped)
     assert out["reductions"] == 16 and out["resident"] == 16          # every surrogate: one reduction, by the persistent kernel
-    assert out["seconds"] < 16 * 0.05                                  # ~15 ms of kernels per surrogate; one give-up alone costs 0.2 s
+    assert out["seconds"] < 10.0                                       # sanity only (~15 ms of kernels per surrogate): the counters above are the property; a tight wall-clock bound flakes on a cold or shared GPU (advisor, round 4)
 
 
 def test_dead_workgroups_of_the_tagged_reduction_do_not_stall_two_lanes():
@@ -416,6 +416,30 @@ def test_rule_n_spectra_do_not_depend_on_the_number_of_lanes():
     for o in outs[1:]:
         for k in outs[0]:
             assert np.array_equal(o[k], outs[0][k]), k
+
+
+@pytest.mark.parametrize("tagged", ["1", "0"])
+def test_persistent_reduction_gives_the_same_bits_for_one_and_two_lanes_in_both_exchange_forms(tagged):
+    """The persistent tridiagonal reduction (eigenproblems of 451 rows: T = 900 complex) inside 1 and 2 surrogate lanes, with
+    the tagged exchange and with the epoch flags (XMCA_TRD_TAGGED=0).  Inside lanes the tagged form deals CONTIGUOUS rows to
+    the workgroups (they leave early); the flags form sums per-workgroup partials of p^H v, so its row ownership must not
+    depend on the lane count (advisor, round 4: it did) - a rank that holds a single run gets one lane, its neighbour three."""
+    import subprocess
+    import tempfile
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from xmca_amd import _hip; h = _hip.Handle(0);"
+            "a, ka = h.rule_n(900, 2200, 1700, 2, True, False, 0, 1, 1e-8, 0, 4, 11, np.float64, 451);"
+            "t = h.timings(); lib = _hip.load_library();"
+            "np.savez(sys.argv[1], a=a, ka=ka, g=np.int64(lib.xmca_persistent_giveups()))" % REPO)
+    outs = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for lanes in ("1", "2"):
+            dst = os.path.join(tmp, "l%s.npz" % lanes)
+            env = dict(os.environ, XMCA_RULE_N_LANES=lanes, XMCA_TRD_TAGGED=tagged)
+            r = subprocess.run([sys.executable, "-c", code, dst], env=env, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs.append(dict(np.load(dst)))
+    assert int(outs[0]["g"]) == 0 and int(outs[1]["g"]) == 0          # (a give-up takes the launch-per-column path: other bits)
+    assert np.array_equal(outs[0]["a"], outs[1]["a"]) and np.array_equal(outs[0]["ka"], outs[1]["ka"])
 
 
 def test_an_error_in_a_lane_is_reported(hip):

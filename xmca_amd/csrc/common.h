@@ -59,7 +59,9 @@ struct DevPool {
     static Registry* r = new Registry;     // never destroyed: pools of static handles may outlive any static of this file
     return *r;
   }
+  int device = 0;                          // the device current when the pool was made: where its blocks live
   DevPool() {
+    (void)hipGetDevice(&device);
     std::lock_guard<std::mutex> g(registry().mu);
     registry().pools.push_back(this);
   }
@@ -67,8 +69,23 @@ struct DevPool {
     // Blocks parked in OTHER pools may still be read by work queued on their streams: wait for the device before any of
     // them is freed (advisor, round 3: this used to rest on hipFree's implicit synchronisation alone).  The registry stays
     // locked for the loop - a pool must not be destroyed under it - but no longer across a device-wide wait per block.
-    (void)hipDeviceSynchronize();
+    // Every pool's OWN device is waited for (advisor, round 4: only the caller's current device was).
+    int orig = 0;
+    (void)hipGetDevice(&orig);
     std::lock_guard<std::mutex> g(registry().mu);
+    std::vector<int> devs;
+    for (DevPool* p : registry().pools) {
+      bool seen = false;
+      for (int d : devs) seen = seen || d == p->device;
+      if (!seen) devs.push_back(p->device);
+    }
+    if (devs.empty()) devs.push_back(orig);
+    int cur = orig;
+    for (int d : devs) {
+      if (d != cur) { (void)hipSetDevice(d); cur = d; }
+      (void)hipDeviceSynchronize();
+    }
+    if (cur != orig) (void)hipSetDevice(orig);
     for (DevPool* p : registry().pools) p->trim();
   }
   std::mutex mu;

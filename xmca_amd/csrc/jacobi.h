@@ -177,6 +177,13 @@ inline void hermitian_evd(hipStream_t st, EvdWorkspace& ws, const double* Ar, co
       for (int i = 0; i + 1 < n && !repeated; ++i) repeated = lam_t[(size_t)i] - lam_t[(size_t)i + 1] <= 2.2e-16 * lmax;
       if (repeated && xmca_trace("solve")) std::fprintf(stderr, "xmca: eigh n = %d: repeated eigenvalues - block Jacobi instead of twisted vectors\n", n);
     }
+    if (repeated) {
+      // The compact-WY factors queued above are not going to be used: wait for them here (second stream) so that they do not
+      // run beside the Jacobi rounds, and leave the workspace as if nothing had been prepared (advisor, round 4).
+      if (ws.trdv.prepared && !ws.trdv.joined && ws.trdv.side) XMCA_HIP(hipStreamSynchronize(ws.trdv.side));
+      ws.trdv.prepared = false;
+      ws.trdv.joined = true;
+    }
     if (!repeated && trd_eigenvectors(st, ws.trd, ws.trdv, ws.gws, P, Ai != nullptr, Zr, Zi, ldz)) {
       XMCA_HIP(hipStreamSynchronize(st));
       lam_host = lam_t;

@@ -193,6 +193,8 @@ class Solver {
     if (!row_norm) n_known = 0;
     if constexpr (std::is_same<TI, float>::value) {
       if (Vt32 && !cplx) {
+        Vt.re.release();                   // (the float64 planes of an earlier model are not part of this result)
+        Vt.im.release();
         float* V = Vt32->ensure((size_t)m * f.N);
         GemmOpts o;
         o.a_kfast = true; o.b_nfast = true;
@@ -238,6 +240,17 @@ class Solver {
     for (EvdInfo& e : out.evd_info) e = EvdInfo();
     solve_core(fields, n_fields, cplx, n_vec_req, out);
     if (n_fields == 2) refine_by_deflation(fields, cplx, out);
+    drop_stale_vectors(out);
+  }
+
+  // A result object keeps float64 planes AND a float32 plane per side; only one of them is written by a solve (vt_f32[side]
+  // says which).  The other one may be left from an earlier model on the same handle - 5 GB at C5 - and must not be reachable
+  // as if it belonged to this result: give it back (advisor, round 4).
+  static void drop_stale_vectors(SolveResult& out) {
+    for (int s = 0; s < 2; ++s) {
+      if (out.vt_f32[s]) { out.Vt[s].re.release(); out.Vt[s].im.release(); }
+      else out.Vt32[s].release();
+    }
   }
 
   // -------------------------------------------------------------------------------------------------------------
@@ -995,6 +1008,8 @@ class Solver {
 
   void solve_analytic(const FieldData<TI>* fields, int n_fields, int n_vec_req, SolveResult& out) {
     out.vt_f32[0] = out.vt_f32[1] = false;     // (complex vectors: float64 planes)
+    out.Vt32[0].release();                     // (a float32 plane left by an earlier model on this handle)
+    out.Vt32[1].release();
     const FieldData<TI>& A = fields[0];
     const int T = (int)A.T;
     const double dof = (double)(T - 1);

@@ -426,6 +426,7 @@ struct TrdSync {
   int poll_delay;         // 64-cycle units to sleep before the first poll (polling early only disturbs the publishers)
   int tag_delay;          // tagged exchange: 64-cycle units to sleep before the loads of a column are requested
   int contiguous;         // rows of a wave: first_res + RR g + t (its RR rows adjacent) instead of first_res + g + NW t (strided)
+  unsigned int spin_limit;  // bounded spins of a wait: 2^20 (~1.5 s) for the first launch of a process on a cold device, 2^17 (~0.2 s) afterwards
 };
 
 
@@ -590,10 +591,10 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
             }
           }
           if (__all(all)) break;
-          if (++spins > (1u << 20)) {
+          if (++spins > S.spin_limit) {
             if (tid == 0 && atomicCAS(S.give_up + 1, 0, 1) == 0) { S.give_up[2] = j; S.give_up[3] = (int)blockIdx.x; }   // (XMCA_TRACE=giveup)
             give_up_sh = 1; break;
-          }       // (~1.5 s) a workgroup is missing: report, never hang.  All persistent launches of THIS process pass one gate (common.h), so only a foreign process can cause it; 0.2 s (round 3) was less than the first launch on a cold device can take
+          }       // a workgroup is missing: report, never hang.  All persistent launches of THIS process pass one gate (common.h), so only a foreign process can cause it; the bound is ~1.5 s for the first launch of a process (0.2 s was less than a first launch on a cold device can take) and ~0.2 s afterwards (TrdSync::spin_limit; advisor, round 4)
           __builtin_amdgcn_s_sleep(1);
         }
       }
@@ -965,7 +966,7 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
             ok &= __hip_atomic_load(flags + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned int)(j + 1);
           if (__all(ok)) break;
           __builtin_amdgcn_s_sleep(1);
-          if (++spins > (1u << 20)) { if (lane == 0) give_up_sh = 1; break; }     // (~1.5 s) a workgroup is missing: report, never hang
+          if (++spins > S.spin_limit) { if (lane == 0) give_up_sh = 1; break; }     // a workgroup is missing: report, never hang (bound: TrdSync::spin_limit)
         }
       }
     }
@@ -1268,7 +1269,6 @@ inline TrdParams trd_reduce(hipStream_t st, TrdWorkspace& ws, const double* Ar, 
     for (int a = 0; a < 2; ++a) for (int c = 0; c < 2; ++c) { S.rowbuf[a][c] = q; q += lv; }
     S.flags = ws.flags.get();
     S.poll_delay = 16;      // (flags form; swept 8...48 in round 3: flat)
-    S.contiguous = in_surrogate_lanes() ? 1 : 0;   // (several surrogates in flight: workgroups that leave early feed the other lanes)
     S.tag_delay = 24;       // swept 0...48 in rounds 3 and 4: flat optimum 20-28, real and complex   // (real: 0 -> 23.4 ms at n = 2920, 4.77 at 1000; 24 -> 22.4, 3.72)
     // column 0 reads its row like every other column: from rowbuf (parity 0)
     // (the tagged form reads row 0 from the working copy: the exchange buffers must start as zeros)
@@ -1277,6 +1277,14 @@ inline TrdParams trd_reduce(hipStream_t st, TrdWorkspace& ws, const double* Ar, 
     // (round 4: the tagged NC = 20 build no longer spills - see the publication of row j + 1 in the kernel) - so: tagged for
     // everything (XMCA_TRD_TAGGED=0 keeps the flags, which the tests still run)
     const bool tagged = [] { const char* e = std::getenv("XMCA_TRD_TAGGED"); return e ? e[0] != '0' : true; }();
+    // Contiguous row ownership only with the tagged exchange: there the arithmetic of a row does not depend on its owner (same
+    // bits for any lane count), and workgroups that leave early feed the other lanes.  In the flags form p^H v is a sum of
+    // per-workgroup partials - regrouping rows would change its order and the bits - and nobody leaves early (advisor, round 4).
+    S.contiguous = (tagged && in_surrogate_lanes()) ? 1 : 0;
+    {
+      static std::atomic<int> warm_launches{0};
+      S.spin_limit = warm_launches.fetch_add(1) == 0 ? (1u << 20) : (1u << 17);
+    }
     if (!tagged) {
       XMCA_HIP(hipMemcpyAsync(S.rowbuf[0][0], P.Ar, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
       if (cplx) XMCA_HIP(hipMemcpyAsync(S.rowbuf[0][1], P.Ai, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
