@@ -162,6 +162,41 @@ def rule_n_model(MCA, h, Tn, Nxn, Nyn):
     return model
 
 
+def native_rccl_check(h, td, rank, world, kw, n_runs, ref, timeout=120.0):
+    """The same sharded rule_n once more through the LIBRARY's own RCCL communicator (C ABI xmca_comm_* / xmca_rule_n_sharded,
+    csrc/comm.h) instead of torch.distributed: the unique id of rank 0 travels through the torch group (or stays local at one
+    rank), every rank calls ncclCommInitRank, and the spectra come back by ONE ncclAllGather.  Reported, never fatal: the
+    attempt runs in a daemon thread with a time limit (a communicator that cannot form must not hang the bench line)."""
+    import threading
+    res = {}
+
+    def work():
+        try:
+            from xmca_amd import _hip, dist
+            uid = _hip.comm_unique_id() if rank == 0 else None
+            if td is not None:
+                obj = [uid]
+                td.broadcast_object_list(obj, src=0)
+                uid = obj[0]
+            c = _hip.Comm(h, uid, rank, world)
+            t0 = time.perf_counter()
+            sp, kept = dist.sharded_rule_n(h, n_runs, comm=c, **kw)
+            dt = time.perf_counter() - t0
+            r, w, n_coll, n_bytes = c.info()
+            c.close()
+            res.update(ok=True, world=int(w), collectives=int(n_coll), bytes_received=int(n_bytes), seconds=dt,
+                       equals_torch_path=bool(np.array_equal(sp, ref[0]) and np.array_equal(kept, ref[1])))
+        except Exception as e:                                    # noqa: BLE001
+            res.update(ok=False, error=repr(e)[:300])
+
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(timeout)
+    if th.is_alive():
+        return {"ok": False, "error": "no result after %.0f s" % timeout, "hung": True}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -179,6 +214,8 @@ def main():
     ap.add_argument("--rule-n-rotated-runs", type=int, default=4,
                     help="runs per GPU of the ROTATED C4 variant (n_rot=20, power=4) with its dropped-run count; 0 = skip")
     ap.add_argument("--no-c5", action="store_true", help="skip the C5 covariance-GEMM roofline leg (5 GB float32 field)")
+    ap.add_argument("--no-native-rccl", action="store_true",
+                    help="skip the cross-check of the rule_n gather through the library's own RCCL communicator (xmca_comm_*)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -208,6 +245,7 @@ def main():
     from xmca_amd import _hip
     from xmca_amd.array import MCA
     h = _hip.Handle(local_rank)
+    hung_thread = False
 
     T, N = args.T, args.N
     X = gen_A(T, N)
@@ -351,6 +389,7 @@ def main():
         model = rule_n_model(MCA, h, Tn, Nxn, Nyn)
         model.rule_n(3 * world, seed=7)               # three untimed surrogates per rank (workspaces of every lane, tile maps)
         n_runs = args.rule_n_runs * world
+        h.reset_timings()
         barrier()
         t0 = time.perf_counter()
         sp = model.rule_n(n_runs, seed=1)
@@ -361,11 +400,42 @@ def main():
             td.all_reduce(tt, op=td.ReduceOp.MAX)
             dt = float(tt.item())
         lanes = int(os.environ.get("XMCA_RULE_N_LANES", "3"))
+        tim_rn = h.timings()
+        for k in ("jacobi_round_kernel_ms", "jacobi_round_kernel_launches", "trd_reduce_kernel_ms", "trd_reduce_calls", "trd_resident_calls"):
+            tim_rn.pop(k, None)
+        # roofline of the rule_n shard (north_star: "... for the Rule-N shard as absolute numbers and as fraction of the HBM/MFMA
+        # roofline"): the only dense contraction of a surrogate is the pair of real Gram products X X^T of its two fields,
+        # T (T + 1) (Nx + Ny) useful float64 flops (one triangle each) - a surrogate cannot take less than that at
+        # the float64 MFMA peak.  `frac` = that ideal time / measured seconds per surrogate and GPU.
+        gram_flops = float(Tn) * (Tn + 1) * (Nxn + Nyn)
+        s_per_surr = dt / args.rule_n_runs
+        rn_roofline = {"bound": "mfma", "unit": "TFLOP/s", "peak": F64_MFMA_PEAK_TF,
+                       "achieved": gram_flops / s_per_surr / 1e12, "frac": gram_flops / s_per_surr / 1e12 / F64_MFMA_PEAK_TF,
+                       "useful_gram_flops_per_surrogate": gram_flops, "ms_per_surrogate_per_gpu": 1e3 * s_per_surr,
+                       "ideal_ms_per_surrogate": 1e3 * gram_flops / (F64_MFMA_PEAK_TF * 1e12),
+                       "stage_ms_per_surrogate_summed_over_lanes": {k: v / args.rule_n_runs for k, v in tim_rn.items()},
+                       "note": "stage times are hipEvent sums over the %d lanes of this rank, which overlap in time: their sum "
+                               "exceeds ms_per_surrogate_per_gpu by what the lanes hide" % lanes}
+        n_out_rn = Tn
+        cap = -(-n_runs // world)
+        collective = {"backend": ("%s (torch.distributed%s)" % (backend, ": RCCL over xGMI" if backend == "nccl" else "")) if td is not None
+                      else "none (single rank: no process group)", "world": world, "collectives_per_call": 2 if td is not None else 0,
+                      "bytes_gathered_per_rank": 8 * cap * (n_out_rn + 1) * world if td is not None else 0}
         extra["rule_n"] = {"config": "C4: MCA T=%d x (%d, %d) f64 surrogates, complexify=True, unrotated; %d runs per GPU, "
                                      "run-sharded, one all_gather (%s); %d surrogates in flight per GPU (XMCA_RULE_N_LANES)" % (
                                          Tn, Nxn, Nyn, args.rule_n_runs, backend if world > 1 else "single rank", lanes),
                            "runs": n_runs, "runs_per_gpu": args.rule_n_runs, "lanes_per_gpu": lanes, "seconds": dt,
-                           "surrogates_per_s": n_runs / dt, "shape": list(sp.shape)}
+                           "surrogates_per_s": n_runs / dt, "shape": list(sp.shape), "roofline": rn_roofline,
+                           "collective": collective}
+        if not args.no_native_rccl and (backend == "nccl" or td is None):
+            # two more surrogates per rank through the torch path and through the native communicator: same bits expected
+            from xmca_amd import dist as _dist
+            kw = dict(T=Tn, Nx=Nxn, Ny=Nyn, n_fields=2, complexify=True, rotated=False, p=Tn, power=0, tol=1e-8, seed=11,
+                      dtype=np.float64, n_out=Tn)
+            ref = _dist.sharded_rule_n(h, 2 * world, **kw)
+            collective["native_rccl"] = native_rccl_check(h, td, rank, world, kw, 2 * world, ref)
+            if collective["native_rccl"].get("hung"):
+                hung_thread = True
         # parity of the timed runs: surrogate (seed 1, run 0) went through the REAL reference once (oracle/make_config_goldens.py
         # c4_run0 on the numpy restatement of the device generator, tests/golden/rule_n_c4_run0.npz).  `sp` is normalised
         # per run (array.py:1767-1769: each column sums to the model's total), so the reference column is normalised alike.
@@ -489,6 +559,9 @@ def main():
         }
         line.update(extra)
         print(json.dumps(line))
+        sys.stdout.flush()
+    if hung_thread:
+        os._exit(0)            # (a native communicator that never formed holds a thread inside RCCL: leave without joining it)
     if td is not None:
         td.destroy_process_group()
 

@@ -41,7 +41,7 @@ typedef struct xmca_handle xmca_handle;
 /* library / device management ------------------------------------------------------------------------- */
 const char* xmca_version(void);
 /* Number of this header's ABI (XMCA_ABI_VERSION): the binding refuses a library built from another revision. */
-#define XMCA_ABI_VERSION 7
+#define XMCA_ABI_VERSION 8
 int xmca_abi_version(void);
 int xmca_device_count(void);
 int xmca_create(int device, xmca_handle** out);
@@ -180,6 +180,33 @@ int xmca_rotate_solved(xmca_handle* h, int p, int power, double tol, int max_ite
 int xmca_rule_n(xmca_handle* h, int64_t T, int64_t Nx, int64_t Ny, int n_fields, const double* hilbert_col, int rotated,
                 int p, int power, double tol, int64_t run_begin, int64_t run_end, uint64_t seed, int dtype,
                 double* spectra_out, int* kept_out, int64_t n_out);
+
+/* Run sharding across the GPUs of a node - the only collective of the path (SURVEY 8(b) `mca_comm_*`, 8(e)).  The reference's
+ * surrogate loop (xmca/array.py:1753-1765) is serial; its runs are independent, so rank r of `world` takes a contiguous block
+ * of run indices on its own GPU and the per-run spectra are combined by ONE ncclAllGather over xGMI (RCCL, bound at run time:
+ * XMCA_ERR_UNSUPPORTED when librccl.so.1 cannot be loaded).  One process per GPU, one communicator per handle's device.
+ *   xmca_comm_unique_id  rank 0 fills XMCA_COMM_ID_BYTES bytes (an ncclUniqueId); the caller ships them to the other ranks
+ *                        (file, MPI, a torch store - the library has no transport of its own besides RCCL).
+ *   xmca_comm_create     collective over all `world` ranks (ncclCommInitRank on the device of `h`).
+ *   xmca_comm_allgather  recv_host[r * count + i] = send_host[i] of rank r (float64, host buffers; staged through device memory).
+ *   xmca_comm_broadcast  `count` float64 of `root` to every rank (used for the seed: every rank must key the generator alike).
+ *   xmca_comm_info       rank, world, number of collectives carried out and bytes received in them (bench.py reports these).
+ *   xmca_rule_n_sharded  xmca_rule_n for runs [0, n_runs) split over the ranks of `comm` (rank r: runs r*n/world ... as
+ *                        xmca_amd/dist.py shard_range), seed taken from rank 0, then the all-gather: every rank receives all
+ *                        n_runs x n_out spectra and kept flags - what array.py:1767-1771 normalises.  The generator is keyed by
+ *                        (seed, run, side): the result does not depend on `world`. */
+#define XMCA_COMM_ID_BYTES 128
+typedef struct xmca_comm xmca_comm;
+int xmca_comm_unique_id(void* id_out);
+int xmca_comm_create(xmca_handle* h, const void* unique_id, int rank, int world, xmca_comm** out);
+void xmca_comm_destroy(xmca_comm* c);
+const char* xmca_comm_last_error(xmca_comm* c);
+int xmca_comm_allgather(xmca_comm* c, const double* send_host, double* recv_host, int64_t count);
+int xmca_comm_broadcast(xmca_comm* c, double* buf_host, int64_t count, int root);
+int xmca_comm_info(xmca_comm* c, int* rank, int* world, int64_t* collectives, int64_t* bytes);
+int xmca_rule_n_sharded(xmca_handle* h, xmca_comm* c, int64_t n_runs, int64_t T, int64_t Nx, int64_t Ny, int n_fields,
+                        const double* hilbert_col, int rotated, int p, int power, double tol, uint64_t seed, int dtype,
+                        double* spectra_out, int* kept_out, int64_t n_out);
 
 /* Surrogate generator on its own (tests): T*N standard normals of (seed, run, side) as float64 on the host. */
 int xmca_surrogate(xmca_handle* h, int64_t n, uint64_t seed, uint32_t run, uint32_t side, double* out);

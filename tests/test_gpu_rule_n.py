@@ -291,6 +291,55 @@ def test_rule_n_through_an_rccl_group_of_one_rank():
     assert np.array_equal(out_rot, m.rule_n(n_runs, seed=77))
 
 
+def test_native_rccl_communicator_of_one_rank():
+    """The library's own RCCL communicator (C ABI xmca_comm_*, csrc/comm.h; SURVEY 8(b) `mca_comm_*`) in a subprocess WITHOUT
+    torch: unique id -> ncclCommInitRank (world 1: all the one-GPU test box allows, RCCL refuses two ranks on a device) ->
+    ncclAllGather / ncclBroadcast round trips, and xmca_rule_n_sharded = xmca_rule_n bit for bit (array.py:1753-1769 sharded);
+    dist.init_native's file rendezvous supplies the id."""
+    import subprocess
+    import tempfile
+    code = ("import sys, os, numpy as np; sys.path.insert(0, %r);"
+            "from xmca_amd import _hip, dist;"
+            "assert 'torch' not in sys.modules;"
+            "h = _hip.Handle(0); c = dist.init_native(h, rank=0, world=1, id_file=sys.argv[1] + '.id');"
+            "x = np.arange(12.0).reshape(3, 4); g = c.allgather(x); assert g.shape == (1, 3, 4) and np.array_equal(g[0], x);"
+            "b = c.broadcast([3.0, 2.0 ** 40 + 1]); assert np.array_equal(b, [3.0, 2.0 ** 40 + 1]);"
+            "args = (150, 400, 300, 2, True, True, 6, 2, 1e-8);"
+            "a, ka = h.rule_n(*args, 0, 5, 2 ** 40 + 77, np.float64, 6);"
+            "s, ks = dist.sharded_rule_n(h, 5, T=150, Nx=400, Ny=300, n_fields=2, complexify=True, rotated=True, p=6, power=2,"
+            " tol=1e-8, seed=2 ** 40 + 77, dtype=np.float64, n_out=6, comm=c);"
+            "assert 'torch' not in sys.modules;"
+            "r, w, n, nb = c.info(); c.close();"
+            "np.savez(sys.argv[1], a=a, ka=ka, s=s, ks=ks, info=np.array([r, w, n, nb]))" % REPO)
+    with tempfile.TemporaryDirectory() as tmp:
+        dst = os.path.join(tmp, "o.npz")
+        r = subprocess.run([sys.executable, "-c", code, dst], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        o = dict(np.load(dst))
+    assert np.array_equal(o["a"], o["s"]) and np.array_equal(o["ka"], o["ks"]) and o["ka"].sum() >= 1
+    rank, world, n_coll, n_bytes = [int(v) for v in o["info"]]
+    assert (rank, world) == (0, 1) and n_coll == 4                      # allgather, broadcast, seed broadcast, spectra all-gather
+    assert n_bytes == 8 * (12 + 2 + 2 + 5 * 7)
+
+
+def test_host_budget_script_on_a_stand_in():
+    """scripts/host_budget.py (the host-CPU budget of 8 ranks x 3 lanes under the 16-CPU quota of a GPU box; the full-size
+    record is profiles/r05_host_budget.json) on its T = 1000 stand-in with 3 ranks sharing the GPU: the legs run, nothing gives
+    up in the single-rank legs, CPU-seconds per surrogate are reported, and two CPUs do not halve the rate."""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(REPO, "scripts", "host_budget.py"), "--small", "--ranks", "3"], cwd=REPO,
+                       capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout[r.stdout.index("{"):])
+    for leg in ("unpinned", "pinned_2_cpus", "spinning_sync_unpinned"):
+        assert out[leg]["giveups"] == 0 and out[leg]["cpu_ms_per_surrogate"] > 0 and out[leg]["surrogates_per_s"] > 1
+    assert out["pinned_2_cpus"]["n_affinity"] == 2
+    assert out["unpinned"]["checksum"] == out["pinned_2_cpus"]["checksum"] == out["spinning_sync_unpinned"]["checksum"]
+    assert out["loss_at_2_cpus"] < 0.5
+    assert out["ranks_sharing_gpu0"]["surrogates"] == 6 and out["ranks_sharing_gpu0"]["cpu_ms_per_surrogate"] > 0
+
+
 def test_bench_py_launches_its_own_ranks():
     """`python bench.py --gpus 2` outside a launcher starts two ranks itself (here both on GPU 0, gloo gather) and reports
     n_gpus = 2 with the run-sharded rule_n - the flow the driver's 2/4/8-GPU scaling runs use (RCCL there)."""

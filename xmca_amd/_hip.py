@@ -55,6 +55,15 @@ SIGNATURES = {
     "xmca_rotate_solved": (_c_int, [_vp, _c_int, _c_int, _c_dbl, _c_int, _vp, _vp, _vp, _vp, _ip]),
     "xmca_rule_n": (_c_int, [_vp, _c_i64, _c_i64, _c_i64, _c_int, _vp, _c_int, _c_int, _c_int, _c_dbl, _c_i64, _c_i64,
                              ctypes.c_uint64, _c_int, _vp, _vp, _c_i64]),
+    "xmca_comm_unique_id": (_c_int, [_vp]),
+    "xmca_comm_create": (_c_int, [_vp, _vp, _c_int, _c_int, ctypes.POINTER(_vp)]),
+    "xmca_comm_destroy": (None, [_vp]),
+    "xmca_comm_last_error": (ctypes.c_char_p, [_vp]),
+    "xmca_comm_allgather": (_c_int, [_vp, _vp, _vp, _c_i64]),
+    "xmca_comm_broadcast": (_c_int, [_vp, _vp, _c_i64, _c_int]),
+    "xmca_comm_info": (_c_int, [_vp, _ip, _ip, ctypes.POINTER(_c_i64), ctypes.POINTER(_c_i64)]),
+    "xmca_rule_n_sharded": (_c_int, [_vp, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _vp, _c_int, _c_int, _c_int, _c_dbl,
+                                     ctypes.c_uint64, _c_int, _vp, _vp, _c_i64]),
     "xmca_surrogate": (_c_int, [_vp, _c_i64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _vp]),
     "xmca_get_timings": (_c_int, [_vp, ctypes.c_char_p, _c_int, _vp, _c_int]),
     "xmca_reset_timings": (_c_int, [_vp]),
@@ -76,7 +85,7 @@ def library_path():
     return _build.LIB
 
 
-ABI_VERSION = 7          # bumped whenever a signature of include/xmca_hip.h changes; checked against xmca_abi_version()
+ABI_VERSION = 8          # bumped whenever a signature of include/xmca_hip.h changes; checked against xmca_abi_version()
 
 
 def load_library():
@@ -408,6 +417,19 @@ class Handle:
                                               _np_dtype_code(dtype), _ptr(spectra), _ptr(kept), n_out))
         return spectra, kept
 
+    def rule_n_sharded(self, comm, n_runs, T, Nx, Ny, n_fields, complexify, rotated, p, power, tol, seed, dtype, n_out):
+        """xmca_rule_n_sharded: this rank's block of the runs [0, n_runs) + ONE ncclAllGather (native RCCL communicator
+        `comm`, see `Comm`); every rank gets all n_runs x n_out spectra and kept flags."""
+        self.release_result()
+        self.fields_owner = None
+        spectra = np.zeros((max(n_runs, 0), n_out), dtype=np.float64)
+        kept = np.zeros(max(n_runs, 0), dtype=np.int32)
+        ht = hilbert_imag_column(T) if complexify else None
+        self._check(self._lib.xmca_rule_n_sharded(self._h, comm._c, int(n_runs), T, Nx, Ny if n_fields == 2 else 0, n_fields,
+                                                  _ptr(ht), int(rotated), int(p), int(power), float(tol), int(seed),
+                                                  _np_dtype_code(dtype), _ptr(spectra), _ptr(kept), n_out))
+        return spectra, kept
+
     def surrogate(self, n, seed, run, side):
         out = np.empty(n, dtype=np.float64)
         self._check(self._lib.xmca_surrogate(self._h, n, int(seed), int(run), int(side), _ptr(out)))
@@ -511,3 +533,60 @@ def default_handle(device=None):
     if device not in _default:
         _default[device] = Handle(device)
     return _default[device]
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """An ncclUniqueId (128 bytes) made by rank 0 for `Comm`; NotImplementedError when RCCL cannot be loaded."""
+    lib = load_library()
+    buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+    rc = lib.xmca_comm_unique_id(buf)
+    if rc != 0:
+        _raise(rc, "xmca_comm_unique_id failed (RCCL not available?)")
+    return buf.raw
+
+
+class Comm:
+    """RCCL communicator of the C ABI (xmca_comm_*): one per process / GPU, created collectively by all `world` ranks from
+    the unique id rank 0 made.  The only collective of the path is the all-gather of the rule_n spectra."""
+
+    def __init__(self, handle, unique_id, rank, world):
+        self._lib = load_library()
+        self._c = None
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError("unique id must be %d bytes" % COMM_ID_BYTES)
+        out = _vp()
+        rc = self._lib.xmca_comm_create(handle._h, ctypes.c_char_p(bytes(unique_id)), int(rank), int(world), ctypes.byref(out))
+        if rc != 0:
+            handle._check(rc)
+        self._c = out
+        self._fin = weakref.finalize(self, self._lib.xmca_comm_destroy, out)
+
+    def _check(self, rc):
+        if rc != 0:
+            _raise(rc, (self._lib.xmca_comm_last_error(self._c) or b"").decode())
+
+    def allgather(self, local):
+        local = np.ascontiguousarray(local, dtype=np.float64)
+        rank, world, _, _ = self.info()
+        out = np.empty((world,) + local.shape, dtype=np.float64)
+        self._check(self._lib.xmca_comm_allgather(self._c, _ptr(local), _ptr(out), local.size))
+        return out
+
+    def broadcast(self, values, root=0):
+        buf = np.ascontiguousarray(values, dtype=np.float64).copy()
+        self._check(self._lib.xmca_comm_broadcast(self._c, _ptr(buf), buf.size, int(root)))
+        return buf
+
+    def info(self):
+        r, w = _c_int(), _c_int()
+        n, b = _c_i64(), _c_i64()
+        self._check(self._lib.xmca_comm_info(self._c, ctypes.byref(r), ctypes.byref(w), ctypes.byref(n), ctypes.byref(b)))
+        return r.value, w.value, n.value, b.value
+
+    def close(self):
+        if self._c is not None:
+            self._fin()
+            self._c = None

@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 REPO = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libxmca_hip.so")
 SOURCES = ["xmca_hip.cpp"]
-HEADERS = ["cholesky.h", "common.h", "fft.h", "gemm.h", "jacobi.h", "jacobi_impl.inc", "kernels.h", "rotate.h", "solver.h", "tridiag.h", "tridiag_vec.h"]
+HEADERS = ["cholesky.h", "comm.h", "common.h", "fft.h", "gemm.h", "jacobi.h", "jacobi_impl.inc", "kernels.h", "rotate.h", "solver.h", "tridiag.h", "tridiag_vec.h"]
 ARCH = "gfx950"
 
 
@@ -39,7 +39,7 @@ def build(force=False, verbose=True):
            "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-but-set-variable",
            "-I", os.path.join(REPO, "include")]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", LIB + ".tmp"]
+    cmd += ["-ldl", "-o", LIB + ".tmp"]          # (dlopen: RCCL is bound at run time, csrc/comm.h)
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -8,6 +8,7 @@
 #include <type_traits>
 
 #include "solver.h"
+#include "comm.h"
 
 using namespace xmca;
 
@@ -1052,6 +1053,160 @@ int xmca_rule_n(xmca_handle* h, int64_t T, int64_t Nx, int64_t Ny, int n_fields,
                         kept_out, n_out);
   h->tm.collect();
   API_END(h)
+}
+
+// ---- RCCL communicator (comm.h) ----------------------------------------------------------------------------------
+#define COMM_BEGIN(c)                                                  \
+  if (!(c)) return XMCA_ERR_INVALID;                                   \
+  try {                                                                \
+    XMCA_HIP(hipSetDevice((c)->device));
+#define COMM_END(c)                                                    \
+  }                                                                    \
+  catch (const ::xmca::Error& e) {                                     \
+    (c)->err = e.what();                                               \
+    (void)hipGetLastError();                                           \
+    return e.code;                                                     \
+  }                                                                    \
+  catch (const std::exception& e) {                                    \
+    (c)->err = std::string("unexpected: ") + e.what();                 \
+    return XMCA_ERR_HIP;                                               \
+  }                                                                    \
+  return XMCA_OK;
+
+int xmca_comm_unique_id(void* id_out) {
+  if (!id_out) return XMCA_ERR_INVALID;
+  RcclApi& api = RcclApi::get();
+  if (!api.lib) return XMCA_ERR_UNSUPPORTED;
+  ncclUniqueId id;
+  if (api.GetUniqueId(&id) != ncclSuccess) return XMCA_ERR_HIP;
+  std::memcpy(id_out, id.internal, XMCA_COMM_ID_BYTES);
+  return XMCA_OK;
+}
+
+int xmca_comm_create(xmca_handle* h, const void* unique_id, int rank, int world, xmca_comm** out) {
+  if (!out) return XMCA_ERR_INVALID;
+  *out = nullptr;
+  API_BEGIN(h)
+  XMCA_CHECK(unique_id && world >= 1 && rank >= 0 && rank < world, XMCA_ERR_INVALID, "comm_create: bad rank / world / id");
+  RcclApi& api = RcclApi::get();
+  api.require();
+  xmca_comm* c = new xmca_comm();
+  c->device = h->device;
+  c->rank = rank;
+  c->world = world;
+  try {
+    XMCA_HIP(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
+    ncclUniqueId id;
+    std::memcpy(id.internal, unique_id, XMCA_COMM_ID_BYTES);
+    api.check(api.CommInitRank(&c->comm, world, id, rank), "ncclCommInitRank");
+  } catch (...) {
+    if (c->st) (void)hipStreamDestroy(c->st);
+    delete c;
+    throw;
+  }
+  *out = c;
+  API_END(h)
+}
+
+void xmca_comm_destroy(xmca_comm* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->st) (void)hipStreamSynchronize(c->st);
+  RcclApi& api = RcclApi::get();
+  if (c->comm && api.lib) (void)api.CommDestroy(c->comm);
+  c->send.release();
+  c->recv.release();
+  if (c->st) (void)hipStreamDestroy(c->st);
+  delete c;
+}
+
+const char* xmca_comm_last_error(xmca_comm* c) { return c ? c->err.c_str() : "null communicator"; }
+
+int xmca_comm_allgather(xmca_comm* c, const double* send_host, double* recv_host, int64_t count) {
+  COMM_BEGIN(c)
+  XMCA_CHECK(count >= 0 && (count == 0 || (send_host && recv_host)), XMCA_ERR_INVALID, "comm_allgather: bad arguments");
+  if (count > 0) {
+    RcclApi& api = RcclApi::get();
+    api.require();
+    double* s = c->send.ensure((size_t)count);
+    double* r = c->recv.ensure((size_t)count * c->world);
+    XMCA_HIP(hipMemcpyAsync(s, send_host, sizeof(double) * count, hipMemcpyHostToDevice, c->st));
+    api.check(api.AllGather(s, r, (size_t)count, ncclFloat64, c->comm, c->st), "ncclAllGather");
+    XMCA_HIP(hipMemcpyAsync(recv_host, r, sizeof(double) * count * c->world, hipMemcpyDeviceToHost, c->st));
+    XMCA_HIP(hipStreamSynchronize(c->st));
+    c->collectives += 1;
+    c->bytes += (long long)sizeof(double) * count * c->world;
+  }
+  COMM_END(c)
+}
+
+int xmca_comm_broadcast(xmca_comm* c, double* buf_host, int64_t count, int root) {
+  COMM_BEGIN(c)
+  XMCA_CHECK(count >= 0 && (count == 0 || buf_host) && root >= 0 && root < c->world, XMCA_ERR_INVALID, "comm_broadcast: bad arguments");
+  if (count > 0) {
+    RcclApi& api = RcclApi::get();
+    api.require();
+    double* s = c->send.ensure((size_t)count);
+    XMCA_HIP(hipMemcpyAsync(s, buf_host, sizeof(double) * count, hipMemcpyHostToDevice, c->st));
+    api.check(api.Broadcast(s, s, (size_t)count, ncclFloat64, root, c->comm, c->st), "ncclBroadcast");
+    XMCA_HIP(hipMemcpyAsync(buf_host, s, sizeof(double) * count, hipMemcpyDeviceToHost, c->st));
+    XMCA_HIP(hipStreamSynchronize(c->st));
+    c->collectives += 1;
+    c->bytes += (long long)sizeof(double) * count;
+  }
+  COMM_END(c)
+}
+
+int xmca_comm_info(xmca_comm* c, int* rank, int* world, int64_t* collectives, int64_t* bytes) {
+  if (!c) return XMCA_ERR_INVALID;
+  if (rank) *rank = c->rank;
+  if (world) *world = c->world;
+  if (collectives) *collectives = c->collectives;
+  if (bytes) *bytes = c->bytes;
+  return XMCA_OK;
+}
+
+int xmca_rule_n_sharded(xmca_handle* h, xmca_comm* c, int64_t n_runs, int64_t T, int64_t Nx, int64_t Ny, int n_fields,
+                        const double* hilbert_col, int rotated, int p, int power, double tol, uint64_t seed, int dtype,
+                        double* spectra_out, int* kept_out, int64_t n_out) {
+  if (!h || !c) return XMCA_ERR_INVALID;
+  if (n_runs < 0 || n_out < 1 || !spectra_out || !kept_out) { h->err = "rule_n_sharded: bad arguments"; return XMCA_ERR_INVALID; }
+  if (c->device != h->device) { h->err = "rule_n_sharded: the communicator belongs to another device"; return XMCA_ERR_INVALID; }
+  // the seed of rank 0 keys every rank's generator (two 32-bit halves: exact in float64)
+  double sd[2] = {(double)(uint32_t)(seed & 0xffffffffu), (double)(uint32_t)(seed >> 32)};
+  int rc = xmca_comm_broadcast(c, sd, 2, 0);
+  if (rc != XMCA_OK) { h->err = "rule_n_sharded: " + c->err; return rc; }
+  seed = (uint64_t)(uint32_t)sd[0] | ((uint64_t)(uint32_t)sd[1] << 32);
+  // contiguous blocks whose sizes differ by at most one (xmca_amd/dist.py shard_range)
+  const int64_t world = c->world, base = n_runs / world, rem = n_runs % world;
+  auto begin_of = [&](int64_t r) { return r * base + std::min<int64_t>(r, rem); };
+  const int64_t b = begin_of(c->rank), e = begin_of(c->rank + 1);
+  const int64_t cap = base + (rem ? 1 : 0);
+  std::vector<double> local((size_t)std::max<int64_t>(cap, 1) * (n_out + 1), 0.0), all;
+  std::vector<double> sp((size_t)std::max<int64_t>(e - b, 1) * n_out, 0.0);
+  std::vector<int> kp((size_t)std::max<int64_t>(e - b, 1), 0);
+  if (e > b) {
+    rc = xmca_rule_n(h, T, Nx, Ny, n_fields, hilbert_col, rotated, p, power, tol, b, e, seed, dtype, sp.data(), kp.data(), n_out);
+    if (rc != XMCA_OK) return rc;      // (every rank fails alike on bad arguments; a device failure of one rank leaves the others in the gather - as with any collective)
+  }
+  for (int64_t i = 0; i < e - b; ++i) {
+    std::memcpy(&local[(size_t)i * (n_out + 1)], &sp[(size_t)i * n_out], sizeof(double) * n_out);
+    local[(size_t)i * (n_out + 1) + n_out] = (double)kp[(size_t)i];
+  }
+  all.assign((size_t)std::max<int64_t>(cap, 1) * (n_out + 1) * world, 0.0);
+  if (cap > 0) {
+    rc = xmca_comm_allgather(c, local.data(), all.data(), cap * (n_out + 1));
+    if (rc != XMCA_OK) { h->err = "rule_n_sharded: " + c->err; return rc; }
+  }
+  for (int64_t r = 0; r < world; ++r) {
+    const int64_t rb = begin_of(r), re = begin_of(r + 1);
+    for (int64_t i = 0; i < re - rb; ++i) {
+      const double* row = &all[((size_t)r * cap + i) * (n_out + 1)];
+      std::memcpy(spectra_out + (rb + i) * n_out, row, sizeof(double) * n_out);
+      kept_out[rb + i] = (int)row[n_out];
+    }
+  }
+  return XMCA_OK;
 }
 
 int xmca_surrogate(xmca_handle* h, int64_t n, uint64_t seed, uint32_t run, uint32_t side, double* out) {

@@ -5,7 +5,17 @@ Surrogate runs are independent (xmca/array.py:1753-1765), so rank r of W process
 (<= 25 x 5000 float64 = 1 MB per rank at the largest configuration) are combined with ONE all_gather
 (RCCL over xGMI when the backend is "nccl", gloo on CPU in the tests).  The device generator is keyed by
 (seed, run, side), so the result does not depend on the number of ranks.
+
+Two transports for that one collective:
+  * a torch.distributed process group, when the caller has initialised one (torchrun; `bench.py`);
+  * the library's own RCCL communicator (C ABI `xmca_comm_*`, `xmca_rule_n_sharded`: include/xmca_hip.h), for callers without
+    torch: `init_native(dev)` reads RANK / WORLD_SIZE, rank 0 makes the ncclUniqueId and passes it through a file
+    (`XMCA_COMM_ID_FILE`, default under /dev/shm keyed by MASTER_PORT: one node, as SURVEY 8(e)), and
+    `sharded_rule_n(..., comm=that)` then runs shard + gather inside the library.
 """
+import os
+import time
+
 import numpy as np
 
 
@@ -50,8 +60,45 @@ def broadcast_seed(seed, dev=None):
     return int(t.item())
 
 
-def sharded_rule_n(dev, n_runs, *, T, Nx, Ny, n_fields, complexify, rotated, p, power, tol, seed, dtype, n_out):
-    """Returns (spectra [n_runs x n_out], kept [n_runs]) assembled on every rank."""
+def init_native(dev, rank=None, world=None, id_file=None, timeout=120.0):
+    """Native RCCL communicator over the ranks of a launcher WITHOUT torch.distributed: rank 0 writes the 128-byte
+    ncclUniqueId to `id_file` (atomically), the others wait for it, all call ncclCommInitRank.  Returns `_hip.Comm`."""
+    from . import _hip
+    rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+    world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
+    if id_file is None:
+        id_file = os.environ.get("XMCA_COMM_ID_FILE") or "/dev/shm/xmca_comm_id_%s_%s" % (
+            os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", str(os.getppid())))
+    if rank == 0:
+        uid = _hip.comm_unique_id()
+        tmp = id_file + ".tmp%d" % os.getpid()
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, id_file)
+    else:
+        t0 = time.time()
+        while not (os.path.exists(id_file) and os.path.getsize(id_file) == _hip.COMM_ID_BYTES):
+            if time.time() - t0 > timeout:
+                raise TimeoutError("no RCCL unique id at %s after %.0f s" % (id_file, timeout))
+            time.sleep(0.01)
+        with open(id_file, "rb") as f:
+            uid = f.read()
+    comm = _hip.Comm(dev, uid, rank, world)          # collective: returns once every rank has joined
+    if rank == 0 and world > 0:
+        try:
+            os.remove(id_file)
+        except OSError:
+            pass
+    return comm
+
+
+def sharded_rule_n(dev, n_runs, *, T, Nx, Ny, n_fields, complexify, rotated, p, power, tol, seed, dtype, n_out, comm=None):
+    """Returns (spectra [n_runs x n_out], kept [n_runs]) assembled on every rank.
+
+    `comm`: a native communicator (`init_native`) - shard, seed broadcast and the all-gather then run inside the library
+    (xmca_rule_n_sharded); otherwise the torch.distributed group when one is initialised; otherwise a single rank."""
+    if comm is not None:
+        return dev.rule_n_sharded(comm, n_runs, T, Nx, Ny, n_fields, complexify, rotated, p, power, tol, seed, dtype, n_out)
     td = _dist()
     rank, world = rank_world()
     seed = broadcast_seed(seed, dev)
