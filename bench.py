@@ -220,6 +220,12 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
+    # stdout carries ONE JSON line and nothing else: RCCL prints a version banner to the C stdout of rank 0 when a communicator
+    # forms (measured: five lines after the JSON line).  File descriptor 1 therefore points at stderr for the whole run and the
+    # line is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -558,8 +564,8 @@ def main():
             "stages_ms": stages, "roofline": roofline, "roofline_gemm": roofline_gemm, "cpu_baseline": cpu,
         }
         line.update(extra)
-        print(json.dumps(line))
         sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if hung_thread:
         os._exit(0)            # (a native communicator that never formed holds a thread inside RCCL: leave without joining it)
     if td is not None:

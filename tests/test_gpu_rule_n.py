@@ -476,7 +476,7 @@ def test_persistent_reduction_gives_the_same_bits_for_one_and_two_lanes_in_both_
     import subprocess
     import tempfile
     code = ("import sys, numpy as np; sys.path.insert(0, %r); from xmca_amd import _hip; h = _hip.Handle(0);"
-            "a, ka = h.rule_n(900, 2200, 1700, 2, True, False, 0, 1, 1e-8, 0, 4, 11, np.float64, 451);"
+            "a, ka = h.rule_n(900, 2200, 1700, 2, True, False, 0, 1, 1e-8, 0, 4, 11, np.float64, 900);"
             "t = h.timings(); lib = _hip.load_library();"
             "np.savez(sys.argv[1], a=a, ka=ka, g=np.int64(lib.xmca_persistent_giveups()))" % REPO)
     outs = []
