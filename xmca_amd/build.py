@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 REPO = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libxmca_hip.so")
 SOURCES = ["xmca_hip.cpp"]
-HEADERS = ["cholesky.h", "comm.h", "common.h", "fft.h", "gemm.h", "jacobi.h", "jacobi_impl.inc", "kernels.h", "rotate.h", "solver.h", "tridiag.h", "tridiag_vec.h"]
+HEADERS = ["chol64.h", "cholesky.h", "comm.h", "common.h", "fft.h", "gemm.h", "jacobi.h", "jacobi_impl.inc", "kernels.h", "rotate.h", "solver.h", "tridiag.h", "tridiag_vec.h"]
 ARCH = "gfx950"
 
 
