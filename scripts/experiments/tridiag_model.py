@@ -157,5 +157,66 @@ def main():
             print("   Newton-Schulz %d: orthogonality %.2e, residual %.2e" % (it + 1, np.max(np.abs(Z.conj().T @ Z - np.eye(n))), np.max(np.linalg.norm(G @ Z - Z * lam_b, axis=0)) / ref[-1]))
 
 
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Two-stage (dense -> band -> tridiagonal) cost model, round 5.  Step counts of the algorithm x unit
+# costs MEASURED on the MI355X with the kernels such a reduction would be built from (profiles/r05_two_stage_gate.md holds the
+# rocprofv3 numbers they come from).  `python scripts/experiments/tridiag_model.py two-stage` prints the table.
+# ----------------------------------------------------------------------------------------------------------------------
+MEASURED_US = {
+    # 64 x 64 factorisation + solve of the attached panel, one launch (chol64_panel_kernel): avg of the Cholesky panel loops
+    "factor64": {"real": 20.6, "complex": 39.6},
+    # split-K product with a 64-wide result + fixed-order sum of the partial tiles (chol64_rowupdate_kernel): the shape of the
+    # panel Gram matrices P^H P, of Z = A Y and of Y^H Z
+    "skinny64": {"real": 23.2, "complex": 40.3},
+    # rank-64 update of the whole trailing matrix (gemm.h, right-looking Cholesky of round 4: traffic-bound); a Hermitian rank-2b
+    # update moves the same bytes once per real plane product
+    "trailing": {"real": 41.2, "complex": 82.4},
+    "launch_gap": 1.4,          # dependent kernel boundary (MI355X_MICROARCH.md price list)
+    "handoff": 1.0,             # cross-CU hand-off of a <= 4 KB record, idle chip (same list)
+    "cu_l2_GBs": 100.0,         # what one CU streams from L2 / MALL with loads in flight (62-122 GB/s in the list)
+}
+
+
+def two_stage_cost(n, b=64, cplx=False, look_ahead=True, lag=2):
+    """Wall-clock model (ms) of stage 1 (panel QR by two Cholesky-QR passes + reconstruction of the block reflector, Z = A Y,
+    W, rank-2b update) and stage 2 (bulge chasing, one workgroup per sweep, `lag` block steps between consecutive sweeps)."""
+    k = "complex" if cplx else "real"
+    u = MEASURED_US
+    panels = (n - 1) // b
+    # ---- stage 1, chain of one panel ----
+    gram = u["skinny64"][k]
+    fact = u["factor64"][k] * max(b, 16) / 64.0   # a chain of b pivots (+ ~4 us of launch, loads and stores, kept in the scaling)
+    panel = 2 * (gram + fact) + fact            # CholQR2 + inverse of I - S^H Q_top (one more 64-step elimination)
+    zprod = u["skinny64"][k]                    # Z = A22 Y, split-K, 64 columns
+    small = u["skinny64"][k] * 0.5 + 10.0       # Y^H Z (64 x 64), W = Z K^H - Y (K M K^H) / 2
+    colup = u["skinny64"][k] * 0.5              # update of the next panel's columns ahead of the rest (look-ahead)
+    trail = u["trailing"][k]
+    gaps = 9 * u["launch_gap"]
+    chain = panel + zprod + small + gaps + (colup + max(0.0, trail - panel) if look_ahead else trail)
+    stage1 = panels * chain * 1e-3
+    # ---- stage 2: n sweeps, sweep s+1 starts `lag` block steps behind sweep s; a block step touches three b x b blocks ----
+    e = 16 if cplx else 8
+    step_bytes = 2 * 3 * b * b * e                                   # read + write of D_k, B_k, B_{k-1}
+    tau = step_bytes / (u["cu_l2_GBs"] * 1e3)                        # us per block step when the blocks stream through one CU
+    stage2_chain = n * (lag * tau + u["handoff"]) * 1e-3             # sweeps on different CUs: one hand-off per sweep on the chain
+    steps = n * n / (2.0 * b)
+    in_flight = max(1.0, n / (lag * b) / 2.0)                        # average number of sweeps alive
+    stage2_tput = steps * tau / in_flight * 1e-3
+    return {"panels": panels, "panel_chain_us": chain, "stage1_ms": stage1, "step_us": tau, "stage2_ms": max(stage2_chain, stage2_tput),
+            "total_ms": stage1 + max(stage2_chain, stage2_tput)}
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "two-stage":
+    print("%-22s %4s %10s %12s %10s %10s %9s   (one-stage, measured)" % ("problem", "b", "panel us", "stage 1 ms", "step us", "stage 2 ms", "total ms"))
+    for name, n, cplx, now in (("C2  n=2920 real", 2920, False, 21.6), ("C4  n=2501 complex", 2501, True, 26.9)):
+        for b in (32, 64, 128):
+            for la in (False, True):
+                r = two_stage_cost(n, b, cplx, la)
+                print("%-22s %4d %10.0f %12.2f %10.2f %10.2f %9.1f   %.1f %s" % (name, b, r["panel_chain_us"], r["stage1_ms"], r["step_us"], r["stage2_ms"],
+                                                                                r["total_ms"], now, "look-ahead" if la else "serial"))
+    sys.exit(0)
+
 if __name__ == "__main__":
     main()
