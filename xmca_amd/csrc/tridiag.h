@@ -125,6 +125,26 @@ __device__ __forceinline__ double trd_block_sum_n(double x, double* red) {
   return s;
 }
 
+// a value every lane holds alike -> scalar registers (the resident kernels have no vector register to spare for column scalars)
+__device__ __forceinline__ double trd_uniform(double x) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
+
+// ... with ONE barrier: the caller hands in a buffer that nobody can still be reading - the resident kernel alternates two by
+// the column parity, and every column has further barriers between two uses of the same one.  Two sums ride on one barrier.
+template <int NWAVES>
+__device__ __forceinline__ void trd_block_sum2_1b(double& a, double& b, double (*buf)[2]) {
+  a = trd_wave_sum_dpp(a);
+  b = trd_wave_sum_dpp(b);
+  if ((threadIdx.x & 63) == 0) { buf[threadIdx.x >> 6][0] = a; buf[threadIdx.x >> 6][1] = b; }
+  __syncthreads();
+  double s = 0.0, t = 0.0;
+#pragma unroll
+  for (int w = 0; w < NWAVES; ++w) { s += buf[w][0]; t += buf[w][1]; }
+  a = s;
+  b = t;
+}
+
 template <bool CPLX, int NS>
 __global__ __launch_bounds__(TRD_THREADS) void trd_step_kernel(TrdParams P, int j, int wgs_prev) {
   extern __shared__ __attribute__((aligned(16))) double trd_lds[];
@@ -452,9 +472,10 @@ constexpr int TRD_RES_THREADS = 256;   // one wave per SIMD: 512 registers per l
 template <bool CPLX, int NC, int RR, bool TAG>
 __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams P, TrdSync S, int first_res) {
   extern __shared__ __attribute__((aligned(16))) double trd_lds[];
-  __shared__ double red[TRD_RES_THREADS / 64];
+  __shared__ double red2[2][2][TRD_RES_THREADS / 64][2];   // [column parity][which sum]: block sums with one barrier each
   __shared__ double gam_sh[TRD_RES_THREADS / 64][2];
   __shared__ double dj_sh;
+  __shared__ double pj_sh[2][2], a0_sh[2][2];                // [column parity]: p_{j-1}[j] and column j's first sub-diagonal entry
   __shared__ double rowpart[2][TRD_RES_THREADS / 64][2];     // streamed rows: the waves' shares of row . v
   __shared__ int give_up_sh;
   constexpr int LV = NC * 128;                     // slots per vector = padded matrix order
@@ -524,6 +545,7 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
   }
   if (tid == 0) give_up_sh = 0;
   double tpr = 0.0, tpi = 0.0;                     // tau of the previous column
+  double spr = 0.0, spi = 0.0;                     // ... and the scale of its reflector: v_{j-1} = u_{j-1} (spr + i spi) beyond its leading 1
   __syncthreads();
 
   const bool prof = P.prof && is_writer && tid == 0;
@@ -548,6 +570,53 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
     if (!TAG && tid < nwg) {
       gr = trd_ld_sc1(gp_r[prev] + tid);
       if (CPLX) gi = trd_ld_sc1(gp_i[prev] + tid);
+    }
+    // ---- the reflector of the PREVIOUS column gets its scale here (round 5): column j-1 left u_{j-1} = x - beta e_j in what is
+    // now bV and ran its pass on that (p = tau s A u is linear in the scale s), so the scaling sits in the wait of the exchange -
+    // the values of column j are still on their way - instead of between two barriers in front of the pass.
+    // v_{j-1} = (0, ..., 0, 1 [slot j], s u [slots above j]); the writer stores it as reflector row j-1.  The thread's own slots stay
+    // in registers (vv): the sums below and the column loop take them from there.  All reads first, then all writes: through
+    // pointers the compiler cannot tell apart every LDS store waits for the load before it and every load for the store - twelve
+    // round trips of ~130 cycles instead of one (what the formation loops of rounds 3-4 spent most of their time on).
+    // No barrier of its own: the one inside the block sum below comes before anybody reads bV.
+    // (the largest complex instantiation - NC = 20: the m = 2501 problems of C3 / C4 - has no registers left for vv next to its
+    //  streamed rows' loads: there the sums and the column loop read bV again, four slots at a time)
+    constexpr bool KEEPV = !(CPLX && NC > 16);
+    double vv_r[NS], vv_i[CPLX ? NS : 1];
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+      const int k = tid + t * TRD_RES_THREADS;
+      const bool in = j > 0 && k > j && k < n;
+      vv_r[t] = in ? bV[0][k] : 0.0;
+      if (CPLX) vv_i[t] = in ? bV[1][k] : 0.0;
+    }
+    if (j > 0) {
+#pragma unroll
+      for (int t = 0; t < NS; ++t) {
+        const int k = tid + t * TRD_RES_THREADS;
+        if (CPLX) {
+          const double xr = vv_r[t], xi = vv_i[t];
+          vv_r[t] = xr * spr - xi * spi;
+          vv_i[t] = xr * spi + xi * spr;
+        } else {
+          vv_r[t] *= spr;
+        }
+        if (k == j) vv_r[t] = 1.0;
+      }
+#pragma unroll
+      for (int t = 0; t < NS; ++t) {
+        const int k = tid + t * TRD_RES_THREADS;
+        if ((t + 1) * TRD_RES_THREADS <= j - 1) continue;      // dead stride: zeros already
+        if (k >= j && k < n) {
+          bV[0][k] = vv_r[t];
+          if (CPLX) bV[1][k] = vv_i[t];
+          if (is_writer && P.Vr) {               // (tau = 0: H = I - the stored reflector is the zero vector)
+            const bool live = tpr != 0.0 || tpi != 0.0;
+            P.Vr[(int64_t)(j - 1) * P.ld + k] = live ? vv_r[t] : 0.0;
+            if (CPLX) P.Vi[(int64_t)(j - 1) * P.ld + k] = live ? vv_i[t] : 0.0;
+          }
+        }
+      }
     }
     if (TAG && j > 0) {
       // (a request that arrives before the values costs a whole round trip: better to ask a little later)
@@ -608,83 +677,100 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
           lq_[t] = trd_untagged(lq_[t]);
         }
         if (k >= j && k < n) {
-          const double vr = bV[0][k], vi = CPLX ? bV[1][k] : 0.0;
+          const double vr = KEEPV ? vv_r[t] : bV[0][k], vi = CPLX ? (KEEPV ? vv_i[t] : bV[1][k]) : 0.0;
           gr += lp_[t] * vr + lq_[t] * vi;              // conj(p) v
           gi += lp_[t] * vi - lq_[t] * vr;
         }
       }
     }
-    gr = trd_block_sum_n<TRD_RES_THREADS / 64>(gr, red);
-    if (CPLX) gi = trd_block_sum_n<TRD_RES_THREADS / 64>(gi, red);
+    // p_{j-1}[j] is needed by every thread in front of the fused loop below (w_{j-1}[j] enters column j): its owner parks it
+    // next to the partial sums - one barrier publishes both
+#pragma unroll
+    for (int t = 0; t < NS; ++t)
+      if (tid + t * TRD_RES_THREADS == j) {
+        pj_sh[cur][0] = lp_[t];
+        pj_sh[cur][1] = CPLX ? lq_[t] : 0.0;
+      }
+    trd_block_sum2_1b<TRD_RES_THREADS / 64>(gr, gi, red2[cur][0]);
     if (TAG && give_up_sh) {
       if (tid == 0) atomicExch(S.give_up, 1);
       break;
     }
     const double ar_ = -0.5 * (tpr * gr - tpi * gi);
     const double ai_ = -0.5 * (tpr * gi + tpi * gr);
-    // w_{j-1} = p_{j-1} + alpha v_{j-1};  conj(row j) parked in bX.  Slots outside [j, n) are written as zeros: dead columns
-    // stay zero in all three vectors, so the pass may touch them.
+    // w_{j-1}[j] = p_{j-1}[j] + alpha v_{j-1}[j]  (v_{j-1}[j] = 1 from column 1 on; 0 in column 0, where p = 0 too)
+    const double vjr = j > 0 ? 1.0 : 0.0, vji = 0.0;
+    const double wjr = pj_sh[cur][0] + ar_ * vjr - ai_ * vji;
+    const double wji = CPLX ? pj_sh[cur][1] + ar_ * vji + ai_ * vjr : 0.0;
+    if (prof) P.prof[8 * j + 1] = __builtin_amdgcn_s_memtime();
+    // ONE loop (round 5; two loops and a barrier before): w_{j-1} = p_{j-1} + alpha v_{j-1} and column j of the current matrix,
+    // x = conj(row j) - v_{j-1} conj(w_{j-1}[j]) - w_{j-1} conj(v_{j-1}[j]).  Slots outside [j, n) are written as zeros: dead columns
+    // stay zero in all three vectors, so the pass may touch them.  Slot j + 1 keeps x[j+1] (the reflector's leading entry
+    // x[j+1] - beta is patched in by the pass: beta needs the norm that is being summed here).
+    // Straight-line code: selects instead of branches (a branch per slot splits the loop into basic blocks, and the dependent
+    // chains of the slots then run one after the other instead of side by side); dead strides are skipped four at a time.
+    double xn2 = 0.0, djv = 0.0, a0v_r = 0.0, a0v_i = 0.0;
 #pragma unroll
-    for (int t = 0; t < NS; ++t) {
-      const int k = tid + t * TRD_RES_THREADS;
-      const bool in = k >= j && k < n;
-      double wr = 0.0, wi = 0.0, xr = 0.0, xi = 0.0;
-      if (in) {
-        const double vr = bV[0][k];
-        xr = lr_[t];
+    for (int t0 = 0; t0 < NS; t0 += 4) {
+      if ((t0 + 4 < NS ? t0 + 4 : NS) * TRD_RES_THREADS + 1 <= j) continue;   // (uniform) every slot of these strides below j - 1: zeros already
+      double gv_r[4], gv_i[4];
+      if constexpr (!KEEPV) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int k = tid + (t0 + u < NS ? t0 + u : NS - 1) * TRD_RES_THREADS;
+          gv_r[u] = bV[0][k];
+          gv_i[u] = CPLX ? bV[1][k] : 0.0;
+        }
+      }
+#pragma unroll
+      for (int t = t0; t < (t0 + 4 < NS ? t0 + 4 : NS); ++t) {
+        const int k = tid + t * TRD_RES_THREADS;
+        const bool in = k >= j && k < n;
+        const double vr = KEEPV ? vv_r[t] : gv_r[t - t0];
+        double wr, wi = 0.0, xr, xi = 0.0;
         if (CPLX) {
-          const double vi = bV[1][k];
+          const double vi = KEEPV ? vv_i[t] : gv_i[t - t0];
           wr = lp_[t] + ar_ * vr - ai_ * vi;
           wi = lq_[t] + ar_ * vi + ai_ * vr;
-          xi = -li_[t];
+          xr = lr_[t] - (vr * wjr + vi * wji) - (wr * vjr + wi * vji);
+          xi = -li_[t] - (vi * wjr - vr * wji) - (wi * vjr - wr * vji);
         } else {
           wr = lp_[t] + ar_ * vr;
+          xr = lr_[t] - vr * wjr - wr * vjr;
         }
-      }
-      bW[0][k] = wr;
-      bX[0][k] = xr;
-      if (CPLX) {
-        bW[1][k] = wi;
-        bX[1][k] = xi;
-      }
-    }
-    __syncthreads();
-    if (prof) P.prof[8 * j + 1] = __builtin_amdgcn_s_memtime();
-    const double wjr = bW[0][j], vjr = bV[0][j];
-    const double wji = CPLX ? bW[1][j] : 0.0, vji = CPLX ? bV[1][j] : 0.0;
-    double xn2 = 0.0;
-#pragma unroll
-    for (int t = 0; t < NS; ++t) {
-      const int k = tid + t * TRD_RES_THREADS;
-      if ((t + 1) * TRD_RES_THREADS <= j) continue;          // dead stride: zeros already
-      double xr = 0.0, xi = 0.0;
-      if (k >= j && k < n) {
-        const double vr = bV[0][k], wr = bW[0][k];
+        wr = in ? wr : 0.0;
+        wi = in ? wi : 0.0;
+        djv = k == j ? xr : djv;
+        a0v_r = k == j + 1 ? xr : a0v_r;
+        a0v_i = k == j + 1 ? xi : a0v_i;
+        const bool keep = in && k != j;
+        xr = keep ? xr : 0.0;
+        xi = keep ? xi : 0.0;
+        const bool tail = in && k > j + 1;
+        xn2 += tail ? xr * xr + xi * xi : 0.0;
+        bW[0][k] = wr;
+        bX[0][k] = xr;
         if (CPLX) {
-          const double vi = bV[1][k], wi = bW[1][k];
-          xr = bX[0][k] - (vr * wjr + vi * wji) - (wr * vjr + wi * vji);
-          xi = bX[1][k] - (vi * wjr - vr * wji) - (wi * vjr - wr * vji);
-        } else {
-          xr = bX[0][k] - vr * wjr - wr * vjr;
-        }
-        if (k == j) {
-          dj_sh = xr;
-          xr = 0.0;
-          xi = 0.0;
-        } else if (k > j + 1) {
-          xn2 += xr * xr + xi * xi;
+          bW[1][k] = wi;
+          bX[1][k] = xi;
         }
       }
-      bX[0][k] = xr;
-      if (CPLX) bX[1][k] = xi;
     }
-    xn2 = trd_block_sum_n<TRD_RES_THREADS / 64>(xn2, red);
+    if (tid == (j & (TRD_RES_THREADS - 1))) dj_sh = djv;
+    if (tid == ((j + 1) & (TRD_RES_THREADS - 1))) {
+      a0_sh[cur][0] = a0v_r;
+      a0_sh[cur][1] = a0v_i;
+    }
+    {
+      double dummy = 0.0;
+      trd_block_sum2_1b<TRD_RES_THREADS / 64>(xn2, dummy, red2[cur][1]);
+    }
     if (prof) P.prof[8 * j + 2] = __builtin_amdgcn_s_memtime();
     if (m == 0) {
       if (is_writer && tid == 0) P.d[j] = dj_sh;
       break;
     }
-    const double a0r = bX[0][j + 1], a0i = CPLX ? bX[1][j + 1] : 0.0;
+    const double a0r = a0_sh[cur][0], a0i = CPLX ? a0_sh[cur][1] : 0.0;
     double beta, tr, ti = 0.0, scr = 0.0, sci = 0.0;
     if (xn2 == 0.0 && a0i == 0.0) {
       beta = a0r;
@@ -698,38 +784,17 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
       scr = dr * dn;
       sci = -di * dn;
     }
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < NS; ++t) {
-      const int k = tid + t * TRD_RES_THREADS;
-      if ((t + 1) * TRD_RES_THREADS <= j) continue;          // dead stride
-      if (k > j && k < n) {
-        double vr, vi = 0.0;
-        if (k == j + 1) {
-          vr = 1.0;
-        } else if (CPLX) {
-          const double xr = bX[0][k], xi = bX[1][k];
-          vr = xr * scr - xi * sci;
-          vi = xr * sci + xi * scr;
-        } else {
-          vr = bX[0][k] * scr;
-        }
-        bX[0][k] = vr;
-        if (CPLX) bX[1][k] = vi;
-        if (is_writer && P.Vr) {               // (tau = 0: H_j = I - the stored reflector is the zero vector)
-          const bool live = tr != 0.0 || ti != 0.0;
-          P.Vr[(int64_t)j * P.ld + k] = live ? vr : 0.0;
-          if (CPLX) P.Vi[(int64_t)j * P.ld + k] = live ? vi : 0.0;
-        }
-      }
-    }
+    // u_j = x - beta e_{j+1};  v_j = s u_j with s = 1 / u_j[j+1] = (scr, sci), so the pass multiplies by u_j and scales the sums
+    // by tau s.  (tau = 0: s = 0, every p is zero whatever u holds.)
+    const double mr_ = trd_uniform(tr * scr - ti * sci), mi_ = trd_uniform(tr * sci + ti * scr);
+    // (what the next column needs of this one's scalars, in scalar registers from here on: tau and the scale are dead in the pass)
+    const double tr_next = trd_uniform(tr), ti_next = trd_uniform(ti), sr_next = trd_uniform(scr), si_next = trd_uniform(sci);
     if (is_writer && tid == 0) {
       P.d[j] = dj_sh;
       P.e[j] = beta;
       P.tau[0][j] = tr;
       if (CPLX) P.tau[1][j] = ti;
     }
-    __syncthreads();
     if (prof) P.prof[8 * j + 3] = __builtin_amdgcn_s_memtime();
     // ---- pass: resident rows in registers, early rows streamed from global memory ----
     // No liveness tests per row: a dead row (i <= j) keeps being updated - nobody reads its p_i (consumers start at j+1),
@@ -738,6 +803,16 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
     const int g0 = ((j + 1) >> 7) / CG;             // groups below hold dead columns only
     const int c0 = (j + 1) >> 7;
     double gwr = 0.0, gwi = 0.0;
+    // bX holds x with x[j+1] as stored; the pass multiplies by u_j = x - beta e_{j+1}.  EVERY wave writes the leading entry itself:
+    // the LDS operations of a wave complete in order, so its own reads below see it without a barrier (four stores of one value).
+    if (lane == 0) bX[0][j + 1] = a0r - beta;
+    // v_j[i] = s u_j[i] (1 at i = j + 1) for the partial sums p^H v of the flags form
+    auto v_of = [&](int i, double& vr, double& vi) {
+      if (i == j + 1) { vr = 1.0; vi = 0.0; return; }
+      const double xr = bX[0][i], xi = CPLX ? bX[1][i] : 0.0;
+      vr = xr * sr_next - xi * si_next;
+      vi = xr * si_next + xi * sr_next;
+    };
     double* const pbr = pub_r[cur];
     double* const pbi = pub_i[cur];
     double* const nrr = rb_r[prev];
@@ -827,14 +902,17 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
         if (wave == 0) {
           const double yr = ((rowpart[par][0][0] + rowpart[par][1][0]) + rowpart[par][2][0]) + rowpart[par][3][0];
           const double yi = CPLX ? ((rowpart[par][0][1] + rowpart[par][1][1]) + rowpart[par][2][1]) + rowpart[par][3][1] : 0.0;
-          const double pr = tr * yr - ti * yi, pi = tr * yi + ti * yr;
-          const double vr = bX[0][i], vi = CPLX ? bX[1][i] : 0.0;
+          const double pr = mr_ * yr - mi_ * yi, pi = mr_ * yi + mi_ * yr;
           if (lane == 0) {
             trd_st_sc1(pbr + i, TAG ? trd_tagged(pr, tgn) : pr);
             if (CPLX) trd_st_sc1(pbi + i, TAG ? trd_tagged(pi, tgn) : pi);
           }
-          gwr += pr * vr + pi * vi;
-          gwi += pr * vi - pi * vr;
+          if constexpr (!TAG) {
+            double vr, vi;
+            v_of(i, vr, vi);
+            gwr += pr * vr + pi * vi;
+            gwi += pr * vi - pi * vr;
+          }
         }
       }
     }
@@ -922,14 +1000,17 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
         if (i < n && i > j) {                              // wave-uniform
           const double yr = trd_wave_sum_dpp(accr[t]);
           const double yi = CPLX ? trd_wave_sum_dpp(acci[t]) : 0.0;
-          const double pr = tr * yr - ti * yi, pi = tr * yi + ti * yr;
-          const double vr = bX[0][i], vi = CPLX ? bX[1][i] : 0.0;
+          const double pr = mr_ * yr - mi_ * yi, pi = mr_ * yi + mi_ * yr;
           if (lane == 0) {
             trd_st_sc1(pbr + i, TAG ? trd_tagged(pr, tgn) : pr);
             if (CPLX) trd_st_sc1(pbi + i, TAG ? trd_tagged(pi, tgn) : pi);
           }
-          gwr += pr * vr + pi * vi;
-          gwi += pr * vi - pi * vr;
+          if constexpr (!TAG) {
+            double vr, vi;
+            v_of(i, vr, vi);
+            gwr += pr * vr + pi * vi;
+            gwi += pr * vi - pi * vr;
+          }
         }
       }
     }
@@ -979,8 +1060,10 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
     // v_j becomes v_{j-1}
     { double* t0 = bV[0]; bV[0] = bX[0]; bX[0] = t0; }
     if (CPLX) { double* t1 = bV[1]; bV[1] = bX[1]; bX[1] = t1; }
-    tpr = tr;
-    tpi = ti;
+    tpr = tr_next;
+    tpi = ti_next;
+    spr = sr_next;
+    spi = si_next;
   }
 }
 
@@ -1269,7 +1352,7 @@ inline TrdParams trd_reduce(hipStream_t st, TrdWorkspace& ws, const double* Ar, 
     for (int a = 0; a < 2; ++a) for (int c = 0; c < 2; ++c) { S.rowbuf[a][c] = q; q += lv; }
     S.flags = ws.flags.get();
     S.poll_delay = 16;      // (flags form; swept 8...48 in round 3: flat)
-    S.tag_delay = 24;       // swept 0...48 in rounds 3 and 4: flat optimum 20-28, real and complex   // (real: 0 -> 23.4 ms at n = 2920, 4.77 at 1000; 24 -> 22.4, 3.72)
+    S.tag_delay = 0;        // round 5: the scaling of the previous reflector fills what used to be the delay (swept again 0...32: 0 for every shape; rounds 3-4: 24 x 64 cycles of sleep)
     // column 0 reads its row like every other column: from rowbuf (parity 0)
     // (the tagged form reads row 0 from the working copy: the exchange buffers must start as zeros)
     // exchange by tagged values or by epoch flags.  Measured with the request delay tuned (XMCA_TRD_TAG_DELAY), tagged / flags:
