@@ -405,7 +405,7 @@ def main():
             tt = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
             td.all_reduce(tt, op=td.ReduceOp.MAX)
             dt = float(tt.item())
-        lanes = int(os.environ.get("XMCA_RULE_N_LANES", "3"))
+        lanes = int(os.environ.get("XMCA_RULE_N_LANES", "2"))
         tim_rn = h.timings()
         for k in ("jacobi_round_kernel_ms", "jacobi_round_kernel_launches", "trd_reduce_kernel_ms", "trd_reduce_calls", "trd_resident_calls"):
             tim_rn.pop(k, None)

@@ -227,7 +227,7 @@ __device__ __forceinline__ bool c64_factor(const C64Lds<CPLX>& S, int wave, int 
 }
 
 // One panel of the Cholesky factorisation in ONE launch: R11 = chol(A11) (the diagonal block (k0, k0), nb <= 64 rows, upper
-// triangle read, written back by workgroup 0 with a zero strictly lower part) and the row panel Y = R11^-H A12 in place
+// triangle read; written by workgroup 0 to the side buffer Dr / Di) and the row panel Y = R11^-H A12 in place
 // (A12 = rows k0 .. k0 + nb - 1, columns k0 + 64 + [0, rest)).  grid = max(1, ceil(rest / 64)):
 //   * EVERY workgroup factors the diagonal block itself in its LDS (the same instructions on the same numbers: the same bits) -
 //     a launch boundary and a round trip of R11 through memory cost more than the 64 pivots do, and nobody waits for anybody;
@@ -237,7 +237,7 @@ __device__ __forceinline__ bool c64_factor(const C64Lds<CPLX>& S, int wave, int 
 // *fail = 1 when a pivot was not positive.
 template <bool CPLX>
 __global__ __launch_bounds__(256) void chol64_panel_kernel(double* __restrict__ Gr, double* __restrict__ Gi, int64_t ld, int k0, int nb, int rest,
-                                                           int* __restrict__ fail) {
+                                                           double* __restrict__ Dr, double* __restrict__ Di, int* __restrict__ fail) {
   extern __shared__ double c64_smem[];
   C64Lds<CPLX> S(c64_smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -265,14 +265,16 @@ __global__ __launch_bounds__(256) void chol64_panel_kernel(double* __restrict__ 
   __syncthreads();
   const bool bad = c64_factor<CPLX>(S, wave, lane);
   if (blockIdx.x == 0) {
+    // R11 goes to a side buffer (Dr / Di: 64 x 64 row-major), NOT over A11: the other workgroups of this launch read A11 whenever
+    // they get their compute unit - with other streams' kernels on the device that can be after this one is done (found in
+    // round 5 as a factorisation that failed now and then inside three surrogate lanes).  cholesky.h copies the diagonal blocks
+    // into the factor at the end.
     if (bad && lane == 0) *fail = 1;
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       const int e = tid + 256 * u, r = e >> 6, c = e & 63;
-      if (r < nb && c < nb) {
-        Gr[(int64_t)(k0 + r) * ld + k0 + c] = (r <= c) ? S.Mr[r * C64_P + c] : 0.0;
-        if constexpr (CPLX) Gi[(int64_t)(k0 + r) * ld + k0 + c] = (r < c) ? S.Mi[r * C64_P + c] : 0.0;
-      }
+      Dr[e] = (r <= c) ? S.Mr[r * C64_P + c] : 0.0;
+      if constexpr (CPLX) Di[e] = (r < c) ? S.Mi[r * C64_P + c] : 0.0;
     }
   }
   if (rest <= 0) return;
@@ -405,7 +407,13 @@ __global__ __launch_bounds__(256) void chol64_rowupdate_kernel(double* __restric
     if (tid == 0) {
       const unsigned int got = __hip_atomic_fetch_add(tickets + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       last_sh = (got == (unsigned int)(nsplit - 1)) ? 1u : 0u;
-      if (last_sh) __hip_atomic_store(tickets + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+      if (last_sh) {
+        // acquire: this XCD's L2 may still hold the slab lines of the PREVIOUS panel's launch (same addresses) - without it the
+        // sums below were wrong now and then once three surrogate lanes interleaved their launches (a non-positive pivot later:
+        // the solver fell back to its other route, results right, 5 of 9 surrogates slow)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(tickets + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+      }
     }
     __syncthreads();
     if (!last_sh) return;

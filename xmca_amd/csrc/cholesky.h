@@ -16,14 +16,20 @@ namespace xmca {
 
 constexpr int CHOL_NB = C64;      // panel width: the 64 x 64 kernels of chol64.h
 
-// zero the strictly lower triangle (the factor is then a dense operand for the GEMMs) and add `delta` to nothing
-__global__ void chol_zero_lower_kernel(double* __restrict__ Gr, double* __restrict__ Gi, int64_t ld, int n) {
+// finish the factor: zero the strictly lower triangle (R is then a dense operand for the GEMMs) and put the factored diagonal
+// blocks (Dr / Di: 64 x 64 per panel, from chol64_panel_kernel) in place
+__global__ void chol_zero_lower_kernel(double* __restrict__ Gr, double* __restrict__ Gi, int64_t ld, int n, const double* __restrict__ Dr,
+                                       const double* __restrict__ Di) {
   const int64_t total = (int64_t)n * n;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int r = (int)(i / n), c = (int)(i % n);
     if (r > c) {
       Gr[(int64_t)r * ld + c] = 0.0;
       if (Gi) Gi[(int64_t)r * ld + c] = 0.0;
+    } else if ((r >> 6) == (c >> 6)) {
+      const int64_t o = (int64_t)(r >> 6) * 4096 + (r & 63) * 64 + (c & 63);
+      Gr[(int64_t)r * ld + c] = Dr[o];
+      if (Gi) Gi[(int64_t)r * ld + c] = Di[o];
     }
   }
 }
@@ -100,14 +106,14 @@ void cgemm(hipStream_t st, GemmWorkspace& ws, const TI* Ar, const TI* Ai, int64_
 
 // one panel: diagonal block + row panel in one launch (chol64.h; the LDS image is dynamic: above 64 KB for complex problems)
 template <bool CPLX>
-static void chol64_launch_panel(hipStream_t st, double* Gr, double* Gi, int64_t ld, int k0, int nb, int rest, int* fail) {
+static void chol64_launch_panel(hipStream_t st, double* Gr, double* Gi, int64_t ld, int k0, int nb, int rest, double* Dr, double* Di, int* fail) {
   static const bool attr = [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol64_panel_kernel<CPLX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64Lds<CPLX>::bytes());
     return true;
   }();
   (void)attr;
   hipLaunchKernelGGL((chol64_panel_kernel<CPLX>), dim3(std::max(1, ceil_div(rest, 64))), dim3(256), C64Lds<CPLX>::bytes(), st, Gr, Gi, ld, k0, nb,
-                     rest, fail);
+                     rest, Dr, Di, fail);
 }
 
 // Blocked Cholesky G + delta I = R^H R (R upper triangular) in place on the planes of an n x n Hermitian matrix whose
@@ -126,6 +132,8 @@ inline bool cholesky_upper(hipStream_t st, GemmWorkspace& ws, double* Gr, double
   unsigned int* tick = tickets.ensure((size_t)n_tick);
   XMCA_HIP(hipMemsetAsync(tick, 0, sizeof(unsigned int) * n_tick, st));
   const int n_cus = ws.cus();
+  DevBuf<double> diag;                      // the factored diagonal blocks, 64 x 64 each (chol64_panel_kernel), copied into R at the end
+  diag.ensure((size_t)n_tick * 4096 * (cplx ? 2 : 1));
   XMCA_HIP(hipMemsetAsync(mx.ensure(1), 0, sizeof(unsigned long long), st));
   XMCA_HIP(hipMemsetAsync(fail.ensure(1), 0, sizeof(int), st));
   hipLaunchKernelGGL(chol_max_diag_kernel, dim3(std::min(ceil_div(n, 256), 64)), dim3(256), 0, st, Gr, ld, n, mx.get());
@@ -157,11 +165,13 @@ inline bool cholesky_upper(hipStream_t st, GemmWorkspace& ws, double* Gr, double
         hipLaunchKernelGGL((chol64_rowupdate_kernel<false>), dim3(ntile * nsplit), dim3(256), 0, st, Gr, (double*)nullptr, ld, k0, nb, n, kchunk,
                            nsplit, sl, tick);
     }
-    if (cplx) chol64_launch_panel<true>(st, Gr, Gi, ld, k0, nb, rest, fail.get());
-    else chol64_launch_panel<false>(st, Gr, nullptr, ld, k0, nb, rest, fail.get());
+    double* dr = diag.get() + (size_t)(k0 / CHOL_NB) * 4096, *di = cplx ? dr + (size_t)n_tick * 4096 : nullptr;
+    if (cplx) chol64_launch_panel<true>(st, Gr, Gi, ld, k0, nb, rest, dr, di, fail.get());
+    else chol64_launch_panel<false>(st, Gr, nullptr, ld, k0, nb, rest, dr, nullptr, fail.get());
     XMCA_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL(chol_zero_lower_kernel, ew_grid((int64_t)n * n), dim3(EW_BLOCK), 0, st, Gr, Gi, ld, n);
+  hipLaunchKernelGGL(chol_zero_lower_kernel, ew_grid((int64_t)n * n), dim3(EW_BLOCK), 0, st, Gr, Gi, ld, n, (const double*)diag.get(),
+                     cplx ? (const double*)(diag.get() + (size_t)n_tick * 4096) : (const double*)nullptr);
   XMCA_HIP(hipGetLastError());
   int failed = 0;
   XMCA_HIP(hipMemcpyAsync(&failed, fail.get(), sizeof(int), hipMemcpyDeviceToHost, st));

@@ -542,7 +542,10 @@ static int lanes_for(int64_t eig_n, int64_t n_runs) {
   static const int lanes_env = [] { const char* e = std::getenv("XMCA_RULE_N_LANES"); return e ? std::max(1, std::min(8, std::atoi(e))) : 0; }();
   // (round 4, contiguous row ownership in the persistent reduction - its workgroups leave from early on: C4 with 2 / 3 / 4 / 5
   //  lanes 48.2 / 45.9 / 45.9 / 47.0 ms per surrogate; C2-shaped EOF and the rotated cases do not care)
-  const int lanes_wanted = lanes_env ? lanes_env : (eig_n >= 2000 ? 3 : 4);
+  // (round 5, left-looking Cholesky of ~80 small launches and the faster reduction: C4 with 1 / 2 / 3 / 4 lanes 19.0 / 22.9 / 20.1 /
+  //  18.7 surrogates/s, C4 rotated 8.8 / 10.9 / 9.3 / 8.0, C2-shaped EOF 42.0 / 44.2 / 44.1 / 43.9 (scripts/lanes_sweep.py): a third
+  //  lane now costs more in interleaved small launches than it fills)
+  const int lanes_wanted = lanes_env ? lanes_env : (eig_n >= 2000 ? 2 : 4);
   return (int)std::min<int64_t>(lanes_wanted, std::max<int64_t>(n_runs, 1));
 }
 
