@@ -291,6 +291,27 @@ def test_rule_n_through_an_rccl_group_of_one_rank():
     assert np.array_equal(out_rot, m.rule_n(n_runs, seed=77))
 
 
+def test_values_only_route_never_falls_back_inside_four_lanes():
+    """Every surrogate of an unrotated two-field rule_n takes the values-only Cholesky route (`values_by_cholesky`): ONE values-only
+    eigenproblem per run, no `eigh` stage.  Inside several lanes the launches of different streams interleave - in round 5 the
+    panel kernel of the factorisation overwrote its diagonal block while late workgroups of the same launch still had to read
+    it, the factorisation then failed now and then, and the solver fell back to its eigen-decomposition route: the spectra
+    stayed right (so no parity test noticed), 5 of 9 surrogates took twice the time.  Counted here: reductions == runs."""
+    import json
+    import subprocess
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r); from xmca_amd import _hip; h = _hip.Handle(0);"
+            "args = (2000, 5000, 4000, 2, True, False, 0, 1, 1e-8);"
+            "h.rule_n(*args, 0, 4, 3, np.float64, 2000); h.reset_timings();"
+            "sp, kept = h.rule_n(*args, 0, 24, 5, np.float64, 2000); t = h.timings();"
+            "print(json.dumps({'keys': sorted(t), 'reductions': t.get('trd_reduce_calls', 0), 'kept': int(kept.sum())}))" % REPO)
+    for lanes in ("4", "3"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, XMCA_RULE_N_LANES=lanes), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = json.loads(r.stdout.splitlines()[-1])
+        assert out["kept"] == 24 and out["reductions"] == 24, out
+        assert "eigh" not in out["keys"] and "cholesky" in out["keys"], out
+
+
 def test_native_rccl_communicator_of_one_rank():
     """The library's own RCCL communicator (C ABI xmca_comm_*, csrc/comm.h; SURVEY 8(b) `mca_comm_*`) in a subprocess WITHOUT
     torch: unique id -> ncclCommInitRank (world 1: all the one-GPU test box allows, RCCL refuses two ranks on a device) ->
