@@ -78,6 +78,7 @@ sys.path.insert(0, REPO)
 
 F64_MFMA_PEAK_TF = 78.6     # MI355X FP64 matrix (= FP64 vector) peak, AMD CDNA4 datasheet; 256 CU * 4 SIMD * 32 FLOP/clk * 2.4 GHz
 F32_MFMA_PEAK_TF = 157.3    # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TF = 2500.0  # dense bf16 MFMA peak (the task's figure; AMD's headline number includes 2:1 sparsity)
 
 
 def gen_A(T=2920, N=10_000, k=20, seed=0):
@@ -108,9 +109,9 @@ def csrc_hash():
     return hh.hexdigest()[:16]
 
 
-PMC_FILE = os.path.join("profiles", "r04_pmc_c2.json")                 # counter passes of the C2 step (scripts/r04_profiles.sh)
-PMC_GRAM_C2 = os.path.join("profiles", "r04_pmc_gram_c2.json")         # ... of the Gram product alone (scripts/gram_only.py c2)
-PMC_GRAM_C5 = os.path.join("profiles", "r04_pmc_gram_c5.json")         # ... and at C5
+PMC_FILE = os.path.join("profiles", "r05_pmc_c2.json")                 # counter passes of the C2 step (scripts/r05_profiles.sh)
+PMC_GRAM_C2 = os.path.join("profiles", "r05_pmc_gram_c2.json")         # ... of the Gram product alone (scripts/gram_only.py c2)
+PMC_GRAM_C5 = os.path.join("profiles", "r05_pmc_gram_c5.json")         # ... and at C5
 
 
 def pmc_traffic(kernel, same_workload, pmc_file=None):
@@ -332,7 +333,7 @@ def main():
                             "peak on MI355X); latency-bound by design: T dependent columns, each one exchange across the chip",
                     "traffic": pmc_traffic("trd_resident_kernel", (T, N) == (2920, 10000) and resident),
                     "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at the default workload, "
-                                      "gfx950-corrected, bytes per launch: %s (scripts/r04_profiles.sh), stamped with the hash "
+                                      "gfx950-corrected, bytes per launch: %s (scripts/r05_profiles.sh), stamped with the hash "
                                       "of xmca_amd/csrc; null when the sources differ or for any other workload" % PMC_FILE,
                     "flops_per_launch": flops_trd, "avg_launch_ms": ms_trd, "launches_per_step": trd_calls / args.steps,
                     "share_of_step": trd_ms / args.steps / ms_per_step, "exchange_us_per_column": 1e3 * ms_trd / T,
@@ -492,6 +493,10 @@ def main():
                                     "bound": "mfma", "bf16x3": x3,
                                     "mfma_flops_issued_per_launch": g5["flops"] * (6.0 if x3 else 1.0),
                                     "achieved": tf5, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf5 / F32_MFMA_PEAK_TF,
+                                    # the same launch against the peak of the instruction it issues: six bf16
+                                    # products per useful float32 product against the dense bf16 MFMA peak
+                                    "frac_issued_vs_bf16_peak": (tf5 * 6.0 / BF16_MFMA_PEAK_TF) if x3 else None,
+                                    "peak_bf16": BF16_MFMA_PEAK_TF,
                                     "traffic": pmc_traffic("gemm_kernel", True, PMC_GRAM_C5),
                                     "traffic_source": "rocprofv3 --pmc passes of scripts/gram_only.py c5, bytes per launch: %s" % PMC_GRAM_C5,
                                     "flops_per_launch": g5["flops"], "avg_launch_ms": g5["kernel_ms"],

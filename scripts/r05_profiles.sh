@@ -1,14 +1,14 @@
 #!/bin/bash
-# Run on the GPU box (gpurun): the artefacts of round 4 under gpurun_out/r04_*; copy what is to be judged into profiles/
-# (scripts/copy_r04_profiles.sh).   scripts/r04_profiles.sh [quick]   quick = bench + C2 kernel stats + the PMC passes only
+# Run on the GPU box (gpurun): the artefacts of round 5 under gpurun_out/r05_*; copy what is to be judged into profiles/
+# (scripts/copy_r05_profiles.sh).   scripts/r05_profiles.sh [quick]   quick = bench + C2 kernel stats + the PMC passes only
 set -u
 REPO=$PWD
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 # 1. the bench line (N = 1)
-python bench.py --steps 10 --warmup 3 > gpurun_out/r04_bench_c2.json 2> gpurun_out/r04_bench_c2.err
+python bench.py --steps 10 --warmup 3 > gpurun_out/r05_bench_c2.json 2> gpurun_out/r05_bench_c2.err
 # 2. rocprofv3 kernel stats of the bench command (C2 step only)
-scripts/profile_cmd.sh r04_c2 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-rule-n --no-e2e --no-c5
+scripts/profile_cmd.sh r05_c2 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-rule-n --no-e2e --no-c5
 # 3. PMC passes (separate runs, kernel-trace only): the C2 step, and the Gram product alone at C2 and C5
 pmc() {   # pmc <tag> <command...>
   tag=$1; shift
@@ -17,7 +17,7 @@ pmc() {   # pmc <tag> <command...>
     rm -rf /tmp/pmc_${tag}_$p
     ( cd /tmp && rocprofv3 --kernel-trace --pmc $pass -d /tmp/pmc_${tag}_$p -o g --output-format csv -- "$@" > /dev/null 2>&1 )
   done
-  python - "$tag" "$*" <<'PY' > gpurun_out/r04_pmc_$tag.json
+  python - "$tag" "$*" <<'PY' > gpurun_out/r05_pmc_$tag.json
 import csv, collections, glob, json, sys
 sys.path.insert(0, ".")
 import bench
@@ -53,11 +53,11 @@ pmc gram_c2 python $REPO/scripts/gram_only.py c2 3
 pmc gram_c5 python $REPO/scripts/gram_only.py c5 2
 if [ "${1:-}" != "quick" ]; then
   # 4. the other configurations through the class + their kernel stats
-  scripts/profile_cmd.sh r04_c3 python scripts/run_config.py C3
-  cp gpurun_out/prof_r04_c3.out gpurun_out/r04_c3_through_class.json
-  scripts/profile_cmd.sh r04_c4 python scripts/rule_n_bench.py
-  cp gpurun_out/prof_r04_c4.out gpurun_out/r04_rule_n_single_gpu.json
-  scripts/profile_cmd.sh r04_c5 python scripts/c5_device_ctor.py
-  cp gpurun_out/prof_r04_c5.out gpurun_out/r04_c5_through_class.json
+  scripts/profile_cmd.sh r05_c3 python scripts/run_config.py C3
+  cp gpurun_out/prof_r05_c3.out gpurun_out/r05_c3_through_class.json
+  scripts/profile_cmd.sh r05_c4 python scripts/rule_n_bench.py
+  cp gpurun_out/prof_r05_c4.out gpurun_out/r05_rule_n_single_gpu.json
+  scripts/profile_cmd.sh r05_c5 python scripts/c5_device_ctor.py
+  cp gpurun_out/prof_r05_c5.out gpurun_out/r05_c5_through_class.json
 fi
-ls -la gpurun_out/r04_* gpurun_out/kstats_r04_*
+ls -la gpurun_out/r05_* gpurun_out/kstats_r05_*

@@ -29,6 +29,14 @@ def _dist():
     return None
 
 
+def _giveups():
+    try:
+        from . import _hip
+        return int(_hip.load_library().xmca_persistent_giveups())
+    except Exception:                                             # noqa: BLE001  (a library without the counter)
+        return 0
+
+
 def rank_world():
     td = _dist()
     if td is None:
@@ -103,7 +111,15 @@ def sharded_rule_n(dev, n_runs, *, T, Nx, Ny, n_fields, complexify, rotated, p, 
     rank, world = rank_world()
     seed = broadcast_seed(seed, dev)
     begin, end = shard_range(n_runs, rank, world)
+    g0 = _giveups()
     spectra, kept = dev.rule_n(T, Nx, Ny, n_fields, complexify, rotated, p, power, tol, begin, end, seed, dtype, n_out)
+    if _giveups() != g0:
+        # a persistent reduction of this rank ran out of its bounded spins (another PROCESS held compute units of this GPU) and was
+        # repeated launch by launch: same spectra to rounding, but another summation order - not the bits a rank on a GPU of its
+        # own produces ("bit reproducibility")
+        import warnings
+        warnings.warn("xmca_amd: %d persistent launch(es) of rank %d were repeated on the launch-per-column path; the spectra of this "
+                      "rank agree with a single-rank run to rounding, not bit for bit" % (_giveups() - g0, rank), RuntimeWarning)
     if td is None:
         return spectra, kept
     # (a one-rank group still runs the collective: the same code path whatever the world size)
