@@ -176,8 +176,11 @@ def native_rccl_check(h, td, rank, world, kw, n_runs, ref, timeout=120.0):
             from xmca_amd import _hip, dist
             uid = _hip.comm_unique_id() if rank == 0 else None
             if td is not None:
+                import torch
+                if td.get_backend() == "nccl":
+                    torch.cuda.set_device(h.device)       # (a new thread starts on device 0: the object broadcast must use this rank's GPU)
                 obj = [uid]
-                td.broadcast_object_list(obj, src=0)
+                td.broadcast_object_list(obj, src=0, device=torch.device("cuda", h.device) if td.get_backend() == "nccl" else None)
                 uid = obj[0]
             c = _hip.Comm(h, uid, rank, world)
             t0 = time.perf_counter()
