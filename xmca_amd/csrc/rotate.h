@@ -851,7 +851,10 @@ __device__ __forceinline__ double rot_wave_sum(double v) {      // (rows added i
 // register r <-> entry [l / 16 + 4 r][l % 16]): ||G||_F, d = Re tr(R^H G), H_kk and the column sums c_k = Re sum_j conj(R_jk)
 // (A0 R)_jk are in-lane sums over r, two cross-row exchanges and DPP row reductions; A0 R = S(A0^T, R) is four (real) MFMAs on
 // the registers the iteration leaves behind.  The block-wide form took 5k cycles for this tail and two barriers for the norm.
-template <bool CPLX>
+// NR = ceil(p / 4) (round 5): the contraction index of product number r is the row l / 16 + 4 r, and the rows from p on are
+// zero padding - the products r >= NR multiply zeros by zeros.  Leaving them out changes no bit and takes a quarter (p <= 12)
+// or half (p <= 8) of the dependent MFMAs out of every Newton-Schulz iteration.
+template <bool CPLX, int NR>
 __device__ __forceinline__ void varimax_polar_wave16_full(const double* __restrict__ Gr, const double* __restrict__ Gi, const int p,
                                                           const double* __restrict__ A0r, const double* __restrict__ A0i,
                                                           double* __restrict__ Rr, double* __restrict__ Ri, double* __restrict__ cvec,
@@ -880,7 +883,7 @@ __device__ __forceinline__ void varimax_polar_wave16_full(const double* __restri
   }
   auto S = [](const double (&P)[4], const double (&Q)[4], d4_t acc, const double sign) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc = Mfma<double>::mma(sign * P[r], Q[r], acc);
+    for (int r = 0; r < NR; ++r) acc = Mfma<double>::mma(sign * P[r], Q[r], acc);
     return acc;
   };
   const d4_t zero = {0, 0, 0, 0};
@@ -1280,7 +1283,12 @@ __device__ __forceinline__ void varimax_polar_step(double* __restrict__ sm, cons
   if (p <= 16) {
     // one wave, everything in registers (it starts again from G in LDS; the block-wide norm is not needed)
     __syncthreads();
-    if (tid < 64) varimax_polar_wave16_full<CPLX>(Gr, Gi, p, A0r, A0i, Rr, Ri, cvec, state, tol);
+    if (tid < 64) {
+      if (p <= 4) varimax_polar_wave16_full<CPLX, 1>(Gr, Gi, p, A0r, A0i, Rr, Ri, cvec, state, tol);
+      else if (p <= 8) varimax_polar_wave16_full<CPLX, 2>(Gr, Gi, p, A0r, A0i, Rr, Ri, cvec, state, tol);
+      else if (p <= 12) varimax_polar_wave16_full<CPLX, 3>(Gr, Gi, p, A0r, A0i, Rr, Ri, cvec, state, tol);
+      else varimax_polar_wave16_full<CPLX, 4>(Gr, Gi, p, A0r, A0i, Rr, Ri, cvec, state, tol);
+    }
     ROT_STAMP(4);
     ROT_STAMP(5);
     return;                        // (the callers synchronise before anybody reads R, c or the state)
