@@ -340,7 +340,7 @@ def test_native_rccl_communicator_of_one_rank():
     assert np.array_equal(o["a"], o["s"]) and np.array_equal(o["ka"], o["ks"]) and o["ka"].sum() >= 1
     rank, world, n_coll, n_bytes = [int(v) for v in o["info"]]
     assert (rank, world) == (0, 1) and n_coll == 4                      # allgather, broadcast, seed broadcast, spectra all-gather
-    assert n_bytes == 8 * (12 + 2 + 2 + 5 * 7)
+    assert n_bytes == 8 * (12 + 2 + 2 + (5 + 1) * 7)                    # (5 runs + the status row) x (6 values + kept)
 
 
 def test_host_budget_script_on_a_stand_in():

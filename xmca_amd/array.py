@@ -981,8 +981,11 @@ class MCA:
                         rows = (pick[:, None] * block_size + np.arange(block_size)[None, :]).reshape(-1)
                         cum = cum[rows]
                     composed[run] = cum
-                spec, kept = dev.bootstrap_runs(n_obs, complexify, composed if on_left else None, composed if on_right else None,
-                                                n_runs, is_rotated, n_rot, max(power, 1), 1e-8, n_out)
+                # (replicates are independent once composed: sharded over the ranks of a torch.distributed job like the Rule-N runs)
+                from . import dist
+                spec, kept = dist.sharded_bootstrap(dev, n_runs, T=n_obs, complexify=complexify, idx_left=composed if on_left else None,
+                                                    idx_right=composed if on_right else None, rotated=is_rotated, p=n_rot,
+                                                    power=max(power, 1), tol=1e-8, n_out=n_out)
                 for run in range(n_runs):
                     if kept[run]:
                         var_surr[mode:, run] = spec[run, :n_modes_max - mode]

@@ -38,6 +38,7 @@ def build(force=False, verbose=True):
     cmd = [_hipcc(), "-x", "hip", "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
            "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-but-set-variable",
            "-I", os.path.join(REPO, "include")]
+    cmd += os.environ.get("XMCA_EXTRA_CXXFLAGS", "").split()      # (experiments: -D switches of a variant build)
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     cmd += ["-ldl", "-o", LIB + ".tmp"]          # (dlopen: RCCL is bound at run time, csrc/comm.h)
     if verbose:

@@ -151,6 +151,23 @@ inline void hermitian_evd(hipStream_t st, EvdWorkspace& ws, const double* Ar, co
   const int trd_min_n = [] { const char* e = std::getenv("XMCA_TRIDIAG_MIN_N"); return e ? std::atoi(e) : 192; }();
   if (!Zr && !nearly_diagonal && trd_enabled() && n >= trd_min_n && trd_fits(n, Ai != nullptr)) {
     TrdParams P = trd_reduce(st, ws.trd, Ar, Ai, n, lda, false);
+    if (xmca_trace("trdsum")) {       // (debug: checksums of the input matrix and of (d, e) - pairs a reduction's output with its input)
+      std::vector<double> in((size_t)n * lda), d(n), e(n);
+      XMCA_HIP(hipStreamSynchronize(st));
+      XMCA_HIP(hipMemcpy(in.data(), Ar, sizeof(double) * in.size(), hipMemcpyDeviceToHost));
+      XMCA_HIP(hipMemcpy(d.data(), P.d, sizeof(double) * n, hipMemcpyDeviceToHost));
+      XMCA_HIP(hipMemcpy(e.data(), P.e, sizeof(double) * n, hipMemcpyDeviceToHost));
+      unsigned long long ci = 1469598103934665603ull, co = ci;
+      for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { unsigned long long b; std::memcpy(&b, &in[(size_t)i * lda + j], 8); ci = (ci ^ b) * 1099511628211ull; }
+      for (int i = 0; i < n; ++i) { unsigned long long b; std::memcpy(&b, &d[i], 8); co = (co ^ b) * 1099511628211ull; if (i + 1 < n) { std::memcpy(&b, &e[i], 8); co = (co ^ b) * 1099511628211ull; } }
+      std::fprintf(stderr, "trdsum n=%d in=%016llx out=%016llx\n", n, ci, co);
+      if (const char* dir = std::getenv("XMCA_TRD_DUMP_DIR")) {      // (d, e) of every distinct (input, output) pair: scripts/de_diff.py
+        char name[512];
+        std::snprintf(name, sizeof(name), "%s/de_%016llx_%016llx.bin", dir, ci, co);
+        if (FILE* f0 = std::fopen(name, "rb")) std::fclose(f0);
+        else if (FILE* f1 = std::fopen(name, "wb")) { std::fwrite(d.data(), 8, n, f1); std::fwrite(e.data(), 8, n, f1); std::fclose(f1); }
+      }
+    }
     trd_eigenvalues(st, ws.trd, P, lam_host, lam_dev, ws.lam_tmp);
     if (info) {
       *info = EvdInfo{};

@@ -447,6 +447,20 @@ struct TrdSync {
   int tag_delay;          // tagged exchange: 64-cycle units to sleep before the loads of a column are requested
   int contiguous;         // rows of a wave: first_res + RR g + t (its RR rows adjacent) instead of first_res + g + NW t (strided)
   unsigned int spin_limit;  // bounded spins of a wait: 2^20 (~1.5 s) for the first launch of a process on a cold device, 2^17 (~0.2 s) afterwards
+  // Chained launches (round 6, tagged form only): a launch reduces the columns [j_begin, j_end) of the problem it is handed and the
+  // next one - a smaller instantiation, re-packed: fewer slots per vector, fuller rows, fewer publishers - continues on the
+  // trailing block.  Handed over: the resident rows (written back to the working copy by the last pass), u_{j-1} and the four
+  // scalars of the previous column (hand_u / hand_s), p_{j-1} and row j in the exchange buffers (they keep their tags: the origin
+  // of a later launch is a multiple of 4 columns further on).  cont != 0: the launch continues a previous one.
+  int j_begin, j_end, cont;
+  double* hand_u[2];      // u_{j_end - 1} by column index (re / im)
+  double* hand_s;         // tau (re, im), scale (re, im) of column j_end - 1
+  // Tagged form, round 6: ONE record per slot and column parity holds what column j gathers for slot k - row j's entry and
+  // p_{j-1}[k], {row, p} (real, 16 bytes) or {row re, row im, p re, p im} (complex, 32 bytes) - so a consumer asks with one (two)
+  // 16-byte load(s) per slot instead of two (four) 8-byte ones: the gather of a column is bound by the number of requests the
+  // 256 workgroups put to the L2s, not by their bytes.  Every double still carries its own tag: a torn record is just a stale half.
+  double* xch;            // parity q at byte offset q * xch_pb (complex: the {re, im} records of the row first, those of p from xch_pb / 2 on)
+  int xch_pb;
 };
 
 
@@ -459,13 +473,46 @@ __device__ __forceinline__ void trd_st_sc1(double* p, double v) { __hip_atomic_s
 // held before is the one of two columns ago: tag(j) = ((j + 1) >> 1) & 1 differs between the two, and the first use of each
 // buffer expects 1 over the zero-filled memory.  The tag bit is cleared on arrival: every workgroup sees the same p and
 // row j, rounded down by at most one ulp - below the rounding of the products they come from.
-__device__ __forceinline__ unsigned int trd_tag_of(int j) { return ((unsigned int)(j + 1) >> 1) & 1u; }
+#ifndef TRD_TAG_MASK
+#define TRD_TAG_MASK 1u
+#endif
+__device__ __forceinline__ unsigned int trd_tag_of(int j) { return ((unsigned int)(j + 1) >> 1) & TRD_TAG_MASK; }
 __device__ __forceinline__ double trd_tagged(double v, unsigned int tag) {
-  return __hiloint2double(__double2hiint(v), (int)(((unsigned int)__double2loint(v) & ~1u) | tag));
+  return __hiloint2double(__double2hiint(v), (int)(((unsigned int)__double2loint(v) & ~TRD_TAG_MASK) | tag));
 }
-__device__ __forceinline__ bool trd_tag_is(double v, unsigned int tag) { return ((unsigned int)__double2loint(v) & 1u) == tag; }
+__device__ __forceinline__ bool trd_tag_is(double v, unsigned int tag) { return ((unsigned int)__double2loint(v) & TRD_TAG_MASK) == tag; }
 __device__ __forceinline__ double trd_untagged(double v) {
-  return __hiloint2double(__double2hiint(v), (int)((unsigned int)__double2loint(v) & ~1u));
+  return __hiloint2double(__double2hiint(v), (int)((unsigned int)__double2loint(v) & ~TRD_TAG_MASK));
+}
+
+// 16-byte agent-scope (sc1) accesses of the exchange records: raw buffer instructions (the only 16-byte form with a cache policy
+// operand); `soff` is wave-uniform.  Host pass: declarations only.
+typedef unsigned int trd_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void trd_ld16_sc1(const double* base, int bytes, int voff, int soff, double& a, double& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(base), 0, bytes, 0x00020000);
+  const trd_u4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, /*sc1*/ 16);
+  a = __hiloint2double((int)q.y, (int)q.x);
+  b = __hiloint2double((int)q.w, (int)q.z);
+#else
+  a = b = 0.0;
+#endif
+}
+// Publication of a complex record {a, b}: one 16-byte agent-scope store.  The whole byte offset goes into the VECTOR offset and the
+// scalar offset field stays the constant 0 ON PURPOSE: `buffer_store_dwordx4` reads its data registers late, and a VALU write of
+// those registers right behind it (here: the tagging of the next pair into the same temporaries) needs wait states.  hipcc
+// (ROCm 7.2) inserts the `s_nop` only for the form WITHOUT a scalar-offset register; with the offset in an SGPR it emitted none,
+// and one reduction in ~400 inside four surrogate lanes - never alone on the GPU, where the store leaves the issue queue at once -
+// then came out different in the 9th digit of d / e (the low dword of the NEXT value in the record).  Found with
+// scripts/det_probe.py / XMCA_TRACE=trdsum (round 6); 8-byte stores: 0 in 2000 reductions, this form: see profiles/r06_trd_determinism.txt.
+__device__ __forceinline__ void trd_st16_sc1(double* base, int bytes, int voff, int soff, double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, 0x00020000);
+  trd_u4 q;
+  q.x = (unsigned int)__double2loint(a); q.y = (unsigned int)__double2hiint(a);
+  q.z = (unsigned int)__double2loint(b); q.w = (unsigned int)__double2hiint(b);
+  __builtin_amdgcn_raw_buffer_store_b128(q, rs, voff + soff, 0, /*sc1*/ 16);
+#endif
 }
 
 constexpr int TRD_RES_THREADS = 256;   // one wave per SIMD: 512 registers per lane for the resident rows
@@ -548,8 +595,22 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
   double spr = 0.0, spi = 0.0;                     // ... and the scale of its reflector: v_{j-1} = u_{j-1} (spr + i spi) beyond its leading 1
   __syncthreads();
 
+  if (TAG && S.cont) {                             // continue a previous launch: u_{j-1} (zero below j) and its scalars
+    for (int s = tid; s < LV; s += TRD_RES_THREADS) {
+      const bool in = s >= S.j_begin && s < n;
+      bV[0][s] = in ? S.hand_u[0][s] : 0.0;
+      if (CPLX) bV[1][s] = in ? S.hand_u[1][s] : 0.0;
+    }
+    tpr = S.hand_s[0]; tpi = CPLX ? S.hand_s[1] : 0.0;
+    spr = S.hand_s[2]; spi = CPLX ? S.hand_s[3] : 0.0;
+    __syncthreads();
+  }
   const bool prof = P.prof && is_writer && tid == 0;
-  for (int j = 0; j < n; ++j) {
+  const bool cont = TAG && S.cont != 0;
+  const int j_end = S.j_end;
+  // (an earlier launch of the chain ran out of its spins: nothing to do, the host starts again)
+  for (int j = (cont && S.give_up[0]) ? j_end : S.j_begin; j < j_end; ++j) {
+    const bool has_prev = j > 0 || cont;
     // Tagged exchange: a workgroup whose rows are all dead has nothing left to publish - so nobody waits for it - and nothing
     // to update: it leaves.  Staying on as a listener was a hazard: it is not flow-controlled, and once it fell two columns
     // behind (a second surrogate lane's kernels on its CU are enough) the live workgroups had overwritten the slots it was
@@ -563,9 +624,9 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
     // zero-filled before the launch and hold row 0 in rowbuf[0]: column 0 needs no special case) ----
     const double* const prr = pub_r[prev];
     const double* const pri = pub_i[prev];
-    // (tagged exchange: row 0 comes from the working copy - a prefilled buffer would carry arbitrary tag bits into column 2)
-    const double* const rwr = (TAG && j == 0) ? P.Ar : rb_r[cur];
-    const double* const rwi = (TAG && j == 0 && CPLX) ? P.Ai : rb_i[cur];
+    // (tagged exchange: row 0 is put into the records of parity 0 by trd_prefill_kernel, tag bits cleared - column 2 expects 1)
+    const double* const rwr = rb_r[cur];
+    const double* const rwi = rb_i[cur];
     double gr = 0.0, gi = 0.0;
     if (!TAG && tid < nwg) {
       gr = trd_ld_sc1(gp_r[prev] + tid);
@@ -586,11 +647,11 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
 #pragma unroll
     for (int t = 0; t < NS; ++t) {
       const int k = tid + t * TRD_RES_THREADS;
-      const bool in = j > 0 && k > j && k < n;
+      const bool in = has_prev && k > j && k < n;
       vv_r[t] = in ? bV[0][k] : 0.0;
       if (CPLX) vv_i[t] = in ? bV[1][k] : 0.0;
     }
-    if (j > 0) {
+    if (has_prev) {
 #pragma unroll
       for (int t = 0; t < NS; ++t) {
         const int k = tid + t * TRD_RES_THREADS;
@@ -618,27 +679,42 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
         }
       }
     }
-    if (TAG && j > 0) {
+    if (TAG && has_prev) {
       // (a request that arrives before the values costs a whole round trip: better to ask a little later)
       for (int q = 0; q < S.tag_delay; ++q) __builtin_amdgcn_s_sleep(1);
     }
     double lr_[NS], li_[NS], lp_[NS], lq_[NS];
-#pragma unroll
-    for (int t = 0; t < NS; ++t) {
-      const int k = tid + t * TRD_RES_THREADS;
-      lr_[t] = trd_ld_sc1(rwr + k);
-      lp_[t] = trd_ld_sc1(prr + k);
-      li_[t] = 0.0;
-      lq_[t] = 0.0;
-      if (CPLX) {
-        li_[t] = trd_ld_sc1(rwi + k);
-        lq_[t] = trd_ld_sc1(pri + k);
+    // (tagged: the records of this column's parity; slot k = tid + 256 t sits 16 * 256 t bytes - a scalar offset - behind the thread's first)
+    const int xrd = cur * S.xch_pb, xwr = prev * S.xch_pb, xbytes = 2 * S.xch_pb, xhalf = S.xch_pb >> 1;
+    auto gather_slot = [&](int t) {
+      if constexpr (TAG) {
+        const int soff = xrd + t * (16 * TRD_RES_THREADS);
+        if constexpr (CPLX) {                      // (complex: the {re, im} records of the row, then - half a parity further on - those of p)
+          trd_ld16_sc1(S.xch, xbytes, tid * 16, soff, lr_[t], li_[t]);
+          trd_ld16_sc1(S.xch, xbytes, tid * 16, soff + xhalf, lp_[t], lq_[t]);
+        } else {
+          trd_ld16_sc1(S.xch, xbytes, tid * 16, soff, lr_[t], lp_[t]);
+          li_[t] = 0.0;
+          lq_[t] = 0.0;
+        }
+      } else {
+        const int k = tid + t * TRD_RES_THREADS;
+        lr_[t] = trd_ld_sc1(rwr + k);
+        lp_[t] = trd_ld_sc1(prr + k);
+        li_[t] = 0.0;
+        lq_[t] = 0.0;
+        if (CPLX) {
+          li_[t] = trd_ld_sc1(rwi + k);
+          lq_[t] = trd_ld_sc1(pri + k);
+        }
       }
-    }
+    };
+#pragma unroll
+    for (int t = 0; t < NS; ++t) gather_slot(t);
     if constexpr (TAG) {
       // wait for the values of column j (tag), each thread for its own slots; p^H v from every workgroup's own copy of v_{j-1}
       const unsigned int tg = trd_tag_of(j);
-      if (j > 0) {
+      if (has_prev) {
         unsigned int spins = 0;
         for (;;) {
           bool all = true;
@@ -650,12 +726,7 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
               if (CPLX) ok = ok && trd_tag_is(li_[t], tg) && trd_tag_is(lq_[t], tg);
               if (!ok) {
                 all = false;
-                lr_[t] = trd_ld_sc1(rwr + k);
-                lp_[t] = trd_ld_sc1(prr + k);
-                if (CPLX) {
-                  li_[t] = trd_ld_sc1(rwi + k);
-                  lq_[t] = trd_ld_sc1(pri + k);
-                }
+                gather_slot(t);
               }
             }
           }
@@ -699,7 +770,7 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
     const double ar_ = -0.5 * (tpr * gr - tpi * gi);
     const double ai_ = -0.5 * (tpr * gi + tpi * gr);
     // w_{j-1}[j] = p_{j-1}[j] + alpha v_{j-1}[j]  (v_{j-1}[j] = 1 from column 1 on; 0 in column 0, where p = 0 too)
-    const double vjr = j > 0 ? 1.0 : 0.0, vji = 0.0;
+    const double vjr = has_prev ? 1.0 : 0.0, vji = 0.0;
     const double wjr = pj_sh[cur][0] + ar_ * vjr - ai_ * vji;
     const double wji = CPLX ? pj_sh[cur][1] + ar_ * vji + ai_ * vjr : 0.0;
     if (prof) P.prof[8 * j + 1] = __builtin_amdgcn_s_memtime();
@@ -818,6 +889,17 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
     double* const nrr = rb_r[prev];
     double* const nri = rb_i[prev];
     const unsigned int tgn = trd_tag_of(j + 1);      // what is published now is consumed by column j+1
+    double* const xnext = TAG ? reinterpret_cast<double*>(reinterpret_cast<char*>(S.xch) + xwr) : nullptr;   // the records column j+1 reads
+    auto publish_p = [&](int i, double pr, double pi) {
+      if constexpr (!TAG) {
+        trd_st_sc1(pbr + i, pr);
+        if (CPLX) trd_st_sc1(pbi + i, pi);
+      } else if constexpr (CPLX) {
+        trd_st16_sc1(S.xch, xbytes, 16 * i, xwr + xhalf, trd_tagged(pr, tgn), trd_tagged(pi, tgn));
+      } else {
+        trd_st_sc1(xnext + 2 * i + 1, trd_tagged(pr, tgn));
+      }
+    };
     // early rows (i < first_res: complex problems of more than 2048 rows), owner WORKGROUP i mod nwg: the same from global
     // memory, the live chunks of the row dealt to the four waves (one wave alone needs five dependent trips to memory for
     // a row of 20 chunks: 9 us, which every other workgroup then waits for).  First, so that the stores are on their way
@@ -875,8 +957,13 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
               sr += a.y * xk.y - b.y * xki.y;
               si += a.y * xki.y + b.y * xk.y;
               if (pubrow) {
-                trd_st_sc1(nri + k, TAG ? trd_tagged(b.x, tgn) : b.x);
-                trd_st_sc1(nri + k + 1, TAG ? trd_tagged(b.y, tgn) : b.y);
+                if constexpr (TAG) {
+                  trd_st16_sc1(S.xch, xbytes, 16 * k, xwr, trd_tagged(a.x, tgn), trd_tagged(b.x, tgn));
+                  trd_st16_sc1(S.xch, xbytes, 16 * k + 16, xwr, trd_tagged(a.y, tgn), trd_tagged(b.y, tgn));
+                } else {
+                  trd_st_sc1(nri + k, b.x);
+                  trd_st_sc1(nri + k + 1, b.y);
+                }
               }
             } else {
               a.x -= svr_ * wk.x + swr_ * vk.x;
@@ -886,8 +973,13 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
               sr += a.y * xk.y;
             }
             if (pubrow) {
-              trd_st_sc1(nrr + k, TAG ? trd_tagged(a.x, tgn) : a.x);
-              trd_st_sc1(nrr + k + 1, TAG ? trd_tagged(a.y, tgn) : a.y);
+              if constexpr (!TAG) {
+                trd_st_sc1(nrr + k, a.x);
+                trd_st_sc1(nrr + k + 1, a.y);
+              } else if constexpr (!CPLX) {
+                trd_st_sc1(xnext + 2 * k, trd_tagged(a.x, tgn));
+                trd_st_sc1(xnext + 2 * k + 2, trd_tagged(a.y, tgn));
+              }
             }
           }
         }
@@ -903,10 +995,7 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
           const double yr = ((rowpart[par][0][0] + rowpart[par][1][0]) + rowpart[par][2][0]) + rowpart[par][3][0];
           const double yi = CPLX ? ((rowpart[par][0][1] + rowpart[par][1][1]) + rowpart[par][2][1]) + rowpart[par][3][1] : 0.0;
           const double pr = mr_ * yr - mi_ * yi, pi = mr_ * yi + mi_ * yr;
-          if (lane == 0) {
-            trd_st_sc1(pbr + i, TAG ? trd_tagged(pr, tgn) : pr);
-            if (CPLX) trd_st_sc1(pbi + i, TAG ? trd_tagged(pi, tgn) : pi);
-          }
+          if (lane == 0) publish_p(i, pr, pi);
           if constexpr (!TAG) {
             double vr, vi;
             v_of(i, vr, vi);
@@ -984,11 +1073,40 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
           for (int c = 0; c < NC; ++c) {
             if (c >= c0) {
               const int k = 128 * c + lane2;
-              trd_st_sc1(nrr + k, TAG ? trd_tagged(ar[t][c].x, tgn) : ar[t][c].x);
-              trd_st_sc1(nrr + k + 1, TAG ? trd_tagged(ar[t][c].y, tgn) : ar[t][c].y);
-              if (CPLX) {
-                trd_st_sc1(nri + k, TAG ? trd_tagged(ai[t][c].x, tgn) : ai[t][c].x);
-                trd_st_sc1(nri + k + 1, TAG ? trd_tagged(ai[t][c].y, tgn) : ai[t][c].y);
+              if constexpr (!TAG) {
+                trd_st_sc1(nrr + k, ar[t][c].x);
+                trd_st_sc1(nrr + k + 1, ar[t][c].y);
+                if (CPLX) {
+                  trd_st_sc1(nri + k, ai[t][c].x);
+                  trd_st_sc1(nri + k + 1, ai[t][c].y);
+                }
+              } else if constexpr (CPLX) {
+                trd_st16_sc1(S.xch, xbytes, 16 * k, xwr, trd_tagged(ar[t][c].x, tgn), trd_tagged(ai[t][c].x, tgn));
+                trd_st16_sc1(S.xch, xbytes, 16 * k + 16, xwr, trd_tagged(ar[t][c].y, tgn), trd_tagged(ai[t][c].y, tgn));
+              } else {
+                trd_st_sc1(xnext + 2 * k, trd_tagged(ar[t][c].x, tgn));
+                trd_st_sc1(xnext + 2 * k + 2, trd_tagged(ar[t][c].y, tgn));
+              }
+            }
+          }
+        }
+      }
+      // In the LAST column of a launch that hands over to another one (chain, TrdSync) the live rows go back to the working
+      // copy: the next launch loads its resident rows from there.
+      if (TAG && j + 1 == j_end && j_end < n) {
+#pragma unroll
+        for (int t = 0; t < RR; ++t) {
+          if (rowi[t] > j && rowi[t] < n) {             // wave-uniform
+            int lane2 = 2 * lane;
+            asm volatile("" : "+v"(lane2));
+            double* const dr_ = P.Ar + (int64_t)rowi[t] * P.ld;
+            double* const di_ = CPLX ? P.Ai + (int64_t)rowi[t] * P.ld : nullptr;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+              if (c >= c0) {
+                const int k = 128 * c + lane2;
+                *reinterpret_cast<double2*>(dr_ + k) = ar[t][c];
+                if (CPLX) *reinterpret_cast<double2*>(di_ + k) = ai[t][c];
               }
             }
           }
@@ -1001,10 +1119,7 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
           const double yr = trd_wave_sum_dpp(accr[t]);
           const double yi = CPLX ? trd_wave_sum_dpp(acci[t]) : 0.0;
           const double pr = mr_ * yr - mi_ * yi, pi = mr_ * yi + mi_ * yr;
-          if (lane == 0) {
-            trd_st_sc1(pbr + i, TAG ? trd_tagged(pr, tgn) : pr);
-            if (CPLX) trd_st_sc1(pbi + i, TAG ? trd_tagged(pi, tgn) : pi);
-          }
+          if (lane == 0) publish_p(i, pr, pi);
           if constexpr (!TAG) {
             double vr, vi;
             v_of(i, vr, vi);
@@ -1057,6 +1172,19 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
       if (tid == 0) atomicExch(S.give_up, 1);
       break;
     }
+    // ---- hand-over to the next launch of the chain (last column of this one, columns remain): u_j and its scalars; the resident
+    // rows went back to the working copy in the pass ----
+    if (TAG && is_writer && j + 1 == j_end && j_end < n) {
+      int s0 = tid;
+      asm volatile("" : "+v"(s0));                 // (the store addresses are loop invariants: not to be hoisted into registers of the column loop)
+      for (int s = s0; s < LV; s += TRD_RES_THREADS) {
+        S.hand_u[0][s] = bX[0][s];
+        if (CPLX) S.hand_u[1][s] = bX[1][s];
+      }
+      if (tid == 0) {
+        S.hand_s[0] = tr_next; S.hand_s[1] = ti_next; S.hand_s[2] = sr_next; S.hand_s[3] = si_next;
+      }
+    }
     // v_j becomes v_{j-1}
     { double* t0 = bV[0]; bV[0] = bX[0]; bX[0] = t0; }
     if (CPLX) { double* t1 = bV[1]; bV[1] = bX[1]; bX[1] = t1; }
@@ -1064,6 +1192,19 @@ __global__ __launch_bounds__(TRD_RES_THREADS) void trd_resident_kernel(TrdParams
     tpi = ti_next;
     spr = sr_next;
     spi = si_next;
+  }
+}
+
+// Tagged exchange: the records of parity 0 start as {row 0 of the working copy, p = 0}, every tag bit cleared (their first rewrite,
+// for column 2, carries tag 1; parity 1 starts as zeros and expects 1 in column 1).
+__global__ void trd_prefill_kernel(const double* __restrict__ Wr, const double* __restrict__ Wi, int n, double* __restrict__ xch) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  if (Wi) {
+    xch[2 * k] = trd_untagged(Wr[k]);
+    xch[2 * k + 1] = trd_untagged(Wi[k]);
+  } else {
+    xch[2 * k] = trd_untagged(Wr[k]);
   }
 }
 
@@ -1227,6 +1368,7 @@ struct TrdWorkspace {
   DevBuf<double> sync;               // exchange buffers of the resident kernel
   DevBuf<unsigned int> flags;
   int resident_used = 0;             // 1: the last reduction ran as the persistent resident kernel, 2: it gave up and was repeated
+  int stages_used = 0;               // launches of the persistent form in the last reduction (1, or the links of the chain)
   // hipEvents around the reduction kernel(s) of every call (the dominant kernel of a solve: bench.py `roofline`)
   hipEvent_t ev[2] = {nullptr, nullptr};
   bool ev_pending = false;
@@ -1297,12 +1439,89 @@ inline int trd_resident_nc(int n, bool cplx) {
   return n <= 24 * 128 ? 24 : 0;
 }
 
+// Chain of persistent launches (round 6).  The per-column cost of the resident kernel grows with the padded order of its
+// instantiation (slots per vector gathered and formed by every workgroup, rows per wave in the pass, publishers in the exchange):
+// a freshly packed n = 1000 launch runs 3.2 us per column where the last 1000 columns of an n = 2920 launch cost 5.5 us each.  So the
+// reduction is handed from instantiation to instantiation as the trailing block shrinks: stage s reduces the columns
+// [j_begin, j_end) of the block that starts at column col0 (a multiple of 256: the slot -> thread and chunk -> lane maps of a
+// column do not change, so every sum keeps its order - the bits do not depend on where the chain is cut).
+// XMCA_TRD_CHAIN=0: one launch.  XMCA_TRD_BREAKS="c1,c2": cut in front of these columns instead (experiments; multiples of 256).
+// bounded spins of the persistent kernel's waits: the long bound for the first persistent launch on EACH device of the process
+// (a cold first launch can take longer than 0.2 s), the short one afterwards (advisor, round 5: one process-wide counter gave the
+// first launch on a second device the short bound)
+inline unsigned int trd_spin_limit() {
+  static std::mutex mu;
+  static std::map<int, int>* warm = new std::map<int, int>;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(mu);
+  return (*warm)[dev]++ == 0 ? (1u << 20) : (1u << 17);
+}
+
+struct TrdStage {
+  int nc, rr;            // instantiation
+  int col0;              // origin of the stage's block
+  int j_begin, j_end;    // columns (global indices) the stage reduces
+};
+// instantiations a LATER stage of a chain may take (tagged form): NC = 4, 8, 12, 16, 20 (real) chunks of 128 columns; the first stage
+// is the one a single launch would take (trd_resident_nc)
+inline int trd_stage_nc(int n, bool cplx) {
+  for (int nc = 4; nc <= (cplx ? 20 : 24); nc += 4)
+    if (n <= nc * 128) return nc;
+  return 0;
+}
+// rows per wave: 256 workgroups x 4 waves x RR rows hold the block (complex: 2 at most - the largest problems stream their first rows)
+inline int trd_stage_rr(int nc, bool cplx) { return cplx ? (nc <= 8 ? 1 : 2) : (nc + 7) / 8; }
+inline std::vector<TrdStage> trd_plan(int n, bool cplx, int nc) {
+  std::vector<TrdStage> st;
+  if (nc <= 0) return st;
+  std::vector<int> cuts;
+  const char* eb = std::getenv("XMCA_TRD_BREAKS");
+  const char* ec = std::getenv("XMCA_TRD_CHAIN");
+  const bool chain = !(ec && ec[0] == '0');
+  const bool tagged = [] { const char* e = std::getenv("XMCA_TRD_TAGGED"); return e ? e[0] != '0' : true; }();
+  if (chain && tagged) {
+    if (eb && eb[0]) {
+      for (const char* q = eb; *q;) {
+        const int c = std::atoi(q);
+        if (c > 0 && c % 256 == 0 && c < n - 256 && (cuts.empty() || c > cuts.back())) cuts.push_back(c);
+        while (*q && *q != ',') ++q;
+        if (*q == ',') ++q;
+      }
+    } else {
+      // as soon as the trailing block fits the next smaller instantiation
+      for (int cnc = nc - 4; cnc >= 4; cnc -= 4) {
+        const int cap = cnc * 128;
+        if (n <= cap) continue;
+        const int c = ((n - cap + 255) / 256) * 256;
+        if (c < n - 256 && (cuts.empty() || c > cuts.back())) cuts.push_back(c);
+      }
+    }
+  }
+  int begin = 0;
+  for (size_t q = 0; q <= cuts.size(); ++q) {
+    const int end = q < cuts.size() ? cuts[q] : n;
+    TrdStage sg{};
+    sg.col0 = begin;
+    sg.nc = (q == 0 && !(chain && tagged)) ? nc : trd_stage_nc(n - begin, cplx);   // (the tagged chain also STARTS in the smallest instantiation that fits)
+    sg.rr = trd_stage_rr(sg.nc, cplx);
+    sg.j_begin = begin;
+    sg.j_end = end;
+    st.push_back(sg);
+    begin = end;
+  }
+  return st;
+}
+
 // Reduces the Hermitian matrix (Ar, Ai) to tridiagonal form on `st`.  Afterwards P.d / P.e hold the tridiagonal of
 // f * A (f = ws.scal[0]), P.tau and (keep_reflectors) ws.V the reflectors.  Returns the parameter block.
 inline TrdParams trd_reduce(hipStream_t st, TrdWorkspace& ws, const double* Ar, const double* Ai, int n, int64_t lda, bool keep_reflectors) {
   const bool cplx = Ai != nullptr;
   const int nc = trd_resident_nc(n, cplx);
-  const int64_t ld = std::max<int64_t>(((int64_t)n + 2 + 15) & ~(int64_t)15, (int64_t)nc * 128);
+  // the launches of the persistent form (one, or a chain of re-packed ones): every stage reads whole 128-column chunks of its rows
+  const std::vector<TrdStage> stages = trd_plan(n, cplx, nc);
+  int64_t ld = std::max<int64_t>(((int64_t)n + 2 + 15) & ~(int64_t)15, (int64_t)nc * 128);
+  for (const TrdStage& sg : stages) ld = std::max<int64_t>(ld, (int64_t)sg.col0 + (int64_t)sg.nc * 128);
   const size_t nv = (size_t)((n + 8 + 15) & ~15);
   ws.W[0].ensure((size_t)n * ld);
   if (cplx) ws.W[1].ensure((size_t)n * ld);
@@ -1335,12 +1554,10 @@ inline TrdParams trd_reduce(hipStream_t st, TrdWorkspace& ws, const double* Ar, 
   if (nc > 0) {
     PersistGate& gate = persist_gate();       // (per device: CU count and the claims of every persistent kernel)
     const int n_cus = gate.n_cus;
-    const int rr = cplx ? (nc == 8 ? 1 : 2) : nc / 8;     // row slots per wave: all of the matrix (real), the last 2048 rows (complex)
-    const int wgs = std::max(1, std::min(std::min(n_cus, TRD_MAX_WGS), ceil_div(n, (TRD_RES_THREADS / 64) * rr)));
-    const int first_res = std::max(0, n - wgs * (TRD_RES_THREADS / 64) * rr);
-    const size_t lv = (size_t)nc * 128;
+    const size_t lv = (size_t)(ld > (int64_t)nc * 128 ? ld : (int64_t)nc * 128);   // slots of an exchange vector: every stage's padded range
     const size_t nvs = std::max(nv, lv);                   // (the prologue loads every slot of a vector, dead or not)
-    const size_t sync_doubles = 4 * nvs + 4 * (size_t)TRD_MAX_WGS + 4 * lv;
+    const size_t rec = cplx ? 4 : 2;                       // doubles per exchange record (tagged form)
+    const size_t sync_doubles = 4 * nvs + 4 * (size_t)TRD_MAX_WGS + 4 * lv + 2 * lv + 8 + 2 * rec * lv;
     ws.sync.ensure(sync_doubles);
     ws.flags.ensure(TRD_MAX_WGS + 32);
     XMCA_HIP(hipMemsetAsync(ws.sync.get(), 0, sizeof(double) * sync_doubles, st));
@@ -1350,6 +1567,10 @@ inline TrdParams trd_reduce(hipStream_t st, TrdWorkspace& ws, const double* Ar, 
     for (int a = 0; a < 2; ++a) for (int c = 0; c < 2; ++c) { S.pub[a][c] = q; q += nvs; }
     for (int a = 0; a < 2; ++a) for (int c = 0; c < 2; ++c) { S.gpart[a][c] = q; q += TRD_MAX_WGS; }
     for (int a = 0; a < 2; ++a) for (int c = 0; c < 2; ++c) { S.rowbuf[a][c] = q; q += lv; }
+    for (int c = 0; c < 2; ++c) { S.hand_u[c] = q; q += lv; }
+    S.hand_s = q; q += 8;
+    S.xch = q;
+    S.xch_pb = (int)(rec * lv * sizeof(double));
     S.flags = ws.flags.get();
     S.poll_delay = 16;      // (flags form; swept 8...48 in round 3: flat)
     S.tag_delay = 0;        // round 5: the scaling of the previous reflector fills what used to be the delay (swept again 0...32: 0 for every shape; rounds 3-4: 24 x 64 cycles of sleep)
@@ -1364,26 +1585,37 @@ inline TrdParams trd_reduce(hipStream_t st, TrdWorkspace& ws, const double* Ar, 
     // bits for any lane count), and workgroups that leave early feed the other lanes.  In the flags form p^H v is a sum of
     // per-workgroup partials - regrouping rows would change its order and the bits - and nobody leaves early (advisor, round 4).
     S.contiguous = (tagged && in_surrogate_lanes()) ? 1 : 0;
-    {
-      static std::atomic<int> warm_launches{0};
-      S.spin_limit = warm_launches.fetch_add(1) == 0 ? (1u << 20) : (1u << 17);
-    }
+    S.spin_limit = trd_spin_limit();
     if (!tagged) {
       XMCA_HIP(hipMemcpyAsync(S.rowbuf[0][0], P.Ar, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
       if (cplx) XMCA_HIP(hipMemcpyAsync(S.rowbuf[0][1], P.Ai, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
     }
+    if (tagged) hipLaunchKernelGGL(trd_prefill_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, P.Ar, P.Ai, n, S.xch);
     S.give_up = reinterpret_cast<int*>(ws.flags.get() + TRD_MAX_WGS);
     using ResFn = void (*)(TrdParams, TrdSync, int);
-    ResFn fn = nullptr;
-    if (tagged) {
-      if (cplx) fn = nc == 8 ? trd_resident_kernel<true, 8, 1, true> : nc == 16 ? trd_resident_kernel<true, 16, 2, true> : trd_resident_kernel<true, 20, 2, true>;
-      else fn = nc == 8 ? trd_resident_kernel<false, 8, 1, true> : nc == 16 ? trd_resident_kernel<false, 16, 2, true> : trd_resident_kernel<false, 24, 3, true>;
-    } else {
-      if (cplx) fn = nc == 8 ? trd_resident_kernel<true, 8, 1, false> : nc == 16 ? trd_resident_kernel<true, 16, 2, false> : trd_resident_kernel<true, 20, 2, false>;
-      else fn = nc == 8 ? trd_resident_kernel<false, 8, 1, false> : nc == 16 ? trd_resident_kernel<false, 16, 2, false> : trd_resident_kernel<false, 24, 3, false>;
-    }
-    const size_t lds = lv * 3 * (cplx ? 2 : 1) * sizeof(double);
-    XMCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    auto pick = [&](int snc) -> ResFn {
+      if (tagged) {
+        if (cplx) {
+          switch (snc) {
+            case 4: return trd_resident_kernel<true, 4, 1, true>;
+            case 8: return trd_resident_kernel<true, 8, 1, true>;
+            case 12: return trd_resident_kernel<true, 12, 2, true>;
+            case 16: return trd_resident_kernel<true, 16, 2, true>;
+            default: return trd_resident_kernel<true, 20, 2, true>;
+          }
+        }
+        switch (snc) {
+          case 4: return trd_resident_kernel<false, 4, 1, true>;
+          case 8: return trd_resident_kernel<false, 8, 1, true>;
+          case 12: return trd_resident_kernel<false, 12, 2, true>;
+          case 16: return trd_resident_kernel<false, 16, 2, true>;
+          case 20: return trd_resident_kernel<false, 20, 3, true>;
+          default: return trd_resident_kernel<false, 24, 3, true>;
+        }
+      }
+      if (cplx) return snc == 8 ? trd_resident_kernel<true, 8, 1, false> : snc == 16 ? trd_resident_kernel<true, 16, 2, false> : trd_resident_kernel<true, 20, 2, false>;
+      return snc == 8 ? trd_resident_kernel<false, 8, 1, false> : snc == 16 ? trd_resident_kernel<false, 16, 2, false> : trd_resident_kernel<false, 24, 3, false>;
+    };
     static const char* prof_file_r = std::getenv("XMCA_TRD_PROF");
     if (prof_file_r) {
       P.prof = ws.prof.ensure((size_t)8 * n);
@@ -1395,7 +1627,34 @@ inline TrdParams trd_reduce(hipStream_t st, TrdWorkspace& ws, const double* Ar, 
       // has finished the reduction
       PersistGate::Claim claim(gate, n_cus);
       ws.ev_begin(st);
-      hipLaunchKernelGGL(fn, dim3(wgs), dim3(TRD_RES_THREADS), lds, st, P, S, first_res);
+      for (size_t q = 0; q < stages.size(); ++q) {
+        const TrdStage& sg = stages[q];
+        const int c0 = sg.col0, ns = n - c0;
+        const int64_t off = (int64_t)c0 * ld + c0;
+        // the stage's view: the trailing block from (c0, c0) on, every vector from slot c0 on
+        TrdParams Pq = P;
+        Pq.n = ns;
+        Pq.Ar = P.Ar + off;
+        if (P.Ai) Pq.Ai = P.Ai + off;
+        Pq.d = P.d + c0; Pq.e = P.e + c0;
+        Pq.tau[0] = P.tau[0] + c0; Pq.tau[1] = P.tau[1] + c0;
+        if (P.Vr) Pq.Vr = P.Vr + off;
+        if (P.Vi) Pq.Vi = P.Vi + off;
+        if (P.prof) Pq.prof = P.prof + (size_t)8 * c0;
+        TrdSync Sq = S;
+        for (int a = 0; a < 2; ++a) for (int c = 0; c < 2; ++c) { Sq.pub[a][c] = S.pub[a][c] + c0; Sq.rowbuf[a][c] = S.rowbuf[a][c] + c0; }
+        Sq.hand_u[0] = S.hand_u[0] + c0; Sq.hand_u[1] = S.hand_u[1] + c0;
+        Sq.xch = S.xch + 2 * (size_t)c0;     // (16 bytes per slot in each block of records)
+        Sq.j_begin = sg.j_begin - c0;
+        Sq.j_end = sg.j_end - c0;
+        Sq.cont = q > 0 ? 1 : 0;
+        const int wgs = std::max(1, std::min(std::min(n_cus, TRD_MAX_WGS), ceil_div(ns, (TRD_RES_THREADS / 64) * sg.rr)));
+        const int first_res = std::max(0, ns - wgs * (TRD_RES_THREADS / 64) * sg.rr);
+        const size_t lds = (size_t)sg.nc * 128 * 3 * (cplx ? 2 : 1) * sizeof(double);
+        ResFn fn = pick(sg.nc);
+        XMCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        hipLaunchKernelGGL(fn, dim3(wgs), dim3(TRD_RES_THREADS), lds, st, Pq, Sq, first_res);
+      }
       ws.ev_end(st);
       XMCA_HIP(hipGetLastError());
       int dbg[4] = {0};
@@ -1403,8 +1662,9 @@ inline TrdParams trd_reduce(hipStream_t st, TrdWorkspace& ws, const double* Ar, 
       XMCA_HIP(hipStreamSynchronize(st));
       gave_up = dbg[0];
       if (gave_up && xmca_trace("giveup"))
-        std::fprintf(stderr, "xmca: trd_resident_kernel: workgroup %d of %d ran out of its spins at column %d of %d\n", dbg[3], wgs, dbg[2], n);
+        std::fprintf(stderr, "xmca: trd_resident_kernel: workgroup %d ran out of its spins at column %d of its launch (n = %d, %d launches)\n", dbg[3], dbg[2], n, (int)stages.size());
     }
+    ws.stages_used = (int)stages.size();
     if (prof_file_r) {
       std::vector<unsigned long long> hp((size_t)8 * n);
       XMCA_HIP(hipMemcpy(hp.data(), P.prof, sizeof(unsigned long long) * hp.size(), hipMemcpyDeviceToHost));

@@ -81,9 +81,19 @@ int xmca_create(int device, xmca_handle** out) {
   // spinning (measured: 1.4 host cores per process while the GPU works -> 0.5; +0.3 ms per 14 ms eigensolve).  For several
   // ranks / surrogate lanes sharing few host cores: a cgroup CPU quota exhausted by spinning threads stalls every thread of
   // the container for the rest of the period ("Host threads"); bench.py sets it for runs of several ranks.
+  // Default (variable unset): blocking whenever the launcher says this process is one of several ranks of a node
+  // (LOCAL_WORLD_SIZE / WORLD_SIZE > 1 - torchrun, mpirun wrappers): 8 spinning ranks need 20 host cores where a GPU box grants 16
+  // (profiles/r05_host_budget.json).  XMCA_BLOCKING_SYNC=0 keeps the spinning waits.
   {
     const char* e = std::getenv("XMCA_BLOCKING_SYNC");
-    if (e && e[0] == '1') { (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync); (void)hipGetLastError(); }
+    bool blocking = e && e[0] == '1';
+    if (!e || !e[0]) {
+      for (const char* name : {"LOCAL_WORLD_SIZE", "WORLD_SIZE"}) {
+        const char* w = std::getenv(name);
+        if (w && std::atoi(w) > 1) blocking = true;
+      }
+    }
+    if (blocking) { (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync); (void)hipGetLastError(); }
   }
   xmca_handle* h = new xmca_handle();
   h->device = device;
@@ -1185,26 +1195,43 @@ int xmca_rule_n_sharded(xmca_handle* h, xmca_comm* c, int64_t n_runs, int64_t T,
   auto begin_of = [&](int64_t r) { return r * base + std::min<int64_t>(r, rem); };
   const int64_t b = begin_of(c->rank), e = begin_of(c->rank + 1);
   const int64_t cap = base + (rem ? 1 : 0);
-  std::vector<double> local((size_t)std::max<int64_t>(cap, 1) * (n_out + 1), 0.0), all;
+  // Payload of a rank: its `cap` rows of (n_out spectra, kept) and ONE status row (status code, 0...).  A rank whose own
+  // runs failed (out of memory, a device error, a lane error) STILL enters the all-gather - with its status - so that no rank is
+  // left waiting in the collective; afterwards every rank returns the same error (round 6; advisor / VERDICT r05: the early
+  // return here left the other ranks in ncclAllGather for good).  A rank without runs (world > n_runs) validates the
+  // arguments through an empty range: a bad-argument failure is the same on every rank.
+  const int64_t rows = cap + 1, width = n_out + 1;
+  std::vector<double> local((size_t)rows * width, 0.0), all;
   std::vector<double> sp((size_t)std::max<int64_t>(e - b, 1) * n_out, 0.0);
   std::vector<int> kp((size_t)std::max<int64_t>(e - b, 1), 0);
-  if (e > b) {
-    rc = xmca_rule_n(h, T, Nx, Ny, n_fields, hilbert_col, rotated, p, power, tol, b, e, seed, dtype, sp.data(), kp.data(), n_out);
-    if (rc != XMCA_OK) return rc;      // (every rank fails alike on bad arguments; a device failure of one rank leaves the others in the gather - as with any collective)
+  int local_rc = xmca_rule_n(h, T, Nx, Ny, n_fields, hilbert_col, rotated, p, power, tol, b, e, seed, dtype, sp.data(), kp.data(), n_out);
+  if (const char* inj = std::getenv("XMCA_TEST_FAIL_RANK"))          // (tests: make this rank's shard fail)
+    if (std::atoi(inj) == c->rank && local_rc == XMCA_OK) { local_rc = XMCA_ERR_NUMERIC; h->err = "rule_n_sharded: injected failure (XMCA_TEST_FAIL_RANK)"; }
+  const std::string local_err = h->err;
+  if (local_rc == XMCA_OK) {
+    for (int64_t i = 0; i < e - b; ++i) {
+      std::memcpy(&local[(size_t)i * width], &sp[(size_t)i * n_out], sizeof(double) * n_out);
+      local[(size_t)i * width + n_out] = (double)kp[(size_t)i];
+    }
   }
-  for (int64_t i = 0; i < e - b; ++i) {
-    std::memcpy(&local[(size_t)i * (n_out + 1)], &sp[(size_t)i * n_out], sizeof(double) * n_out);
-    local[(size_t)i * (n_out + 1) + n_out] = (double)kp[(size_t)i];
+  local[(size_t)cap * width] = (double)local_rc;
+  all.assign((size_t)rows * width * world, 0.0);
+  rc = xmca_comm_allgather(c, local.data(), all.data(), rows * width);
+  if (rc != XMCA_OK) { h->err = "rule_n_sharded: " + c->err + (local_rc != XMCA_OK ? " (and this rank's shard failed: " + local_err + ")" : ""); return rc; }
+  int first_bad = -1, bad_rc = XMCA_OK;
+  for (int64_t r = 0; r < world; ++r) {
+    const int st_r = (int)all[((size_t)r * rows + cap) * width];
+    if (st_r != XMCA_OK && first_bad < 0) { first_bad = (int)r; bad_rc = st_r; }
   }
-  all.assign((size_t)std::max<int64_t>(cap, 1) * (n_out + 1) * world, 0.0);
-  if (cap > 0) {
-    rc = xmca_comm_allgather(c, local.data(), all.data(), cap * (n_out + 1));
-    if (rc != XMCA_OK) { h->err = "rule_n_sharded: " + c->err; return rc; }
+  if (first_bad >= 0) {
+    h->err = "rule_n_sharded: the shard of rank " + std::to_string(first_bad) + " failed with status " + std::to_string(bad_rc) +
+             (local_rc != XMCA_OK ? " (this rank: " + local_err + ")" : " (this rank's shard was fine)");
+    return local_rc != XMCA_OK ? local_rc : bad_rc;
   }
   for (int64_t r = 0; r < world; ++r) {
     const int64_t rb = begin_of(r), re = begin_of(r + 1);
     for (int64_t i = 0; i < re - rb; ++i) {
-      const double* row = &all[((size_t)r * cap + i) * (n_out + 1)];
+      const double* row = &all[((size_t)r * rows + i) * width];
       std::memcpy(spectra_out + (rb + i) * n_out, row, sizeof(double) * n_out);
       kept_out[rb + i] = (int)row[n_out];
     }
