@@ -41,7 +41,7 @@ typedef struct xmca_handle xmca_handle;
 /* library / device management ------------------------------------------------------------------------- */
 const char* xmca_version(void);
 /* Number of this header's ABI (XMCA_ABI_VERSION): the binding refuses a library built from another revision. */
-#define XMCA_ABI_VERSION 8
+#define XMCA_ABI_VERSION 9
 int xmca_abi_version(void);
 int xmca_device_count(void);
 int xmca_create(int device, xmca_handle** out);
@@ -78,6 +78,13 @@ int xmca_get_singular_values(xmca_handle* h, double* out, int64_t n);
 /* MCA._V[key] (array.py:584), transposed: out[m * N + n] = V[n][m] for m < n_modes; complex interleaved when
  * the model is complex.  dtype selects float32 / float64 components. */
 int xmca_get_vectors(xmca_handle* h, int side, void* out, int64_t n_modes, int dtype);
+
+/* MCA.eofs() in its final layout (array.py:615-646 `_get_V` + :676-721 `_get_eofs`, ABI 9): out[n * q + c] = sum_{mm < m} V[n][mm] W[mm][c]
+ * for the N grid points of `side` - the N x q array the reference reshapes to (space..., modes) - mixed on the device from the
+ * resident mode-major vectors, so the host neither transposes nor multiplies an N x m array.  W (m x q, row-major float64,
+ * complex interleaved when w_is_complex) = diag(sqrt(s)) R / norm with its columns ordered and selected by the caller; W == NULL:
+ * the first q = m vectors as they are.  The output is complex (interleaved) when the model or W is; dtype: float32 / float64. */
+int xmca_get_eofs(xmca_handle* h, int side, const double* W, int64_t m, int64_t q, int w_is_complex, void* out, int dtype);
 
 /* PC projection of MCA._get_U (xmca/array.py:648-674, the product `fields[k] @ V[k]`): U = X~ V with X~ the field of
  * `side` as solve() saw it - still resident on the device; the analytic signal X + i Ht X when complexify was
@@ -216,6 +223,11 @@ int xmca_surrogate(xmca_handle* h, int64_t n, uint64_t seed, uint32_t run, uint3
  * jacobi_fused_round_kernel launches, events around the rounds of every sweep) and "jacobi_round_kernel_launches"
  * (their number, in the ms array). */
 int xmca_get_timings(xmca_handle* h, char* names, int names_len, double* ms, int max_n);
+
+/* The kernels of the handle's last tridiagonal reduction by name (instantiation, column range of every launch of the chain), e.g.
+ * "chain of 6 persistent launches: trd_resident_kernel<real,NC=24,RR=3,tagged> columns [0,512) -> ...": what `roofline.kernel`
+ * of bench.py reports (ABI 9; until round 5 the bench synthesised the name from T).  Returns the length of the description. */
+int xmca_get_reduction_info(xmca_handle* h, char* out, int out_len);
 int xmca_reset_timings(xmca_handle* h);
 
 /* Batched complex DFT used by the analytic-signal path (csrc/fft.h), host in / host out, for the parity tests:

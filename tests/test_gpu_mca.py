@@ -760,3 +760,32 @@ def test_device_memory_pool_is_reported_and_trimmed(hip):
     b.solve(complexify=True)
     assert np.array_equal(b._singular_values, s1)
     assert h.pool_bytes() > 0
+
+
+@pytest.mark.parametrize("name,cplx,rot", [("sst_prcp", False, None), ("sst_prcp", True, (6, 2)), ("wide_both", False, (5, 1)),
+                                           ("wide_both_f32", False, None), ("wide_both_f32", True, (4, 1)), ("c5_scaled", False, (10, 1))])
+def test_eofs_assembled_on_the_device_equal_the_host_path(name, cplx, rot):
+    """Round 6: while the vectors of solve() are still resident, `eofs()` is mixed on the device into its
+    final (space..., modes) layout - `(V sqrt(s)) @ R / norm`, variance order, slice; array.py:615-646, 676-721 - by
+    `xmca_get_eofs`; once they have been fetched the numpy path of `_get_V` runs.  Same numbers, shape, dtype and NaN mask
+    (sst has masked grid points), for counts, slices, scalings and a phase shift."""
+    fields = make_input(name)
+    m = MCA(*fields)
+    m.solve(complexify=cplx)
+    if rot:
+        m.rotate(*rot)
+    asks = [dict(n=3), dict(n=None), dict(n=slice(2, 4)), dict(n=4, rotated=False), dict(n=3, scaling='max'), dict(n=3, scaling='eigen'),
+            dict(n=2, scaling='std', phase_shift=0.7 if cplx else 0)]
+    assert set(m._V._pending) == set(m._keys)
+    fast = [m.eofs(**kw) for kw in asks]
+    assert set(m._V._pending) == set(m._keys)               # nothing was fetched in full: every call took the device path
+    m._V.materialize()
+    for kw, f in zip(asks, fast):
+        slow = m.eofs(**kw)                                 # vectors on the host now: the numpy path
+        for k in m._keys:
+            assert f[k].shape == slow[k].shape and f[k].dtype == slow[k].dtype, (kw, k, f[k].dtype, slow[k].dtype)
+            assert np.array_equal(np.isnan(f[k]), np.isnan(slow[k]))
+            ok = ~np.isnan(slow[k])
+            # (float32 models: the host path mixes the vectors as fetched - rounded to float32 -, the device the resident ones)
+            tol = 2e-6 if m._V._dtype == np.float32 else 1e-12
+            assert np.max(np.abs(f[k][ok] - slow[k][ok])) <= tol * max(np.max(np.abs(slow[k][ok])), 1e-300), (kw, k)

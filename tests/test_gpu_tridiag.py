@@ -219,3 +219,30 @@ def test_values_of_a_model_do_not_depend_on_the_eigensolver(monkeypatch):
     b = m.rule_n(3, seed=11)
     keep = b > 1e-9 * b[0]
     assert a.shape == b.shape and np.max(np.abs(a[keep] - b[keep]) / b[keep]) < 1e-9
+
+
+@pytest.mark.parametrize("n,cplx", [(700, False), (1300, True), (1500, False), (2501, True), (2920, False)])
+def test_chain_of_repacked_launches_gives_the_bits_of_one_launch(hip, monkeypatch, n, cplx):
+    """Round 6: the persistent reduction is handed from instantiation to instantiation as the trailing block shrinks (tridiag.h
+    `trd_plan`: cuts at multiples of 256 columns, so every sum keeps its order).  The tridiagonal matrix - hence every eigenvalue -
+    must not depend on where the chain is cut: default cuts, one launch, and two hand-picked cuts give identical bits, with and
+    without reflectors kept (the vectors' route); against LAPACK as before."""
+    G = _gram(n, cplx, spikes=8)
+    monkeypatch.setenv("XMCA_TRD_CHAIN", "1")
+    lam, _ = hip.eigh(G, vectors=False)
+    monkeypatch.setenv("XMCA_TRD_CHAIN", "0")
+    one, _ = hip.eigh(G, vectors=False)
+    monkeypatch.setenv("XMCA_TRD_CHAIN", "1")
+    monkeypatch.setenv("XMCA_TRD_BREAKS", "256,768" if n > 1100 else "256")
+    cut, _ = hip.eigh(G, vectors=False)
+    assert np.array_equal(lam, one) and np.array_equal(lam, cut)
+    ref = np.linalg.eigvalsh(G)[::-1]
+    assert np.max(np.abs(lam - ref)) < 1e-13 * ref[0]
+    if n <= 1500:
+        monkeypatch.delenv("XMCA_TRD_BREAKS")
+        monkeypatch.setenv("XMCA_TRIDIAG_VEC_MIN_N", "2")
+        lam_v, U = hip.eigh(G)
+        assert hip.last_eigh_info["tridiag"] == 1
+        assert np.max(np.abs(lam_v - ref)) < 1e-13 * ref[0]
+        assert np.max(np.abs(U.conj().T @ U - np.eye(n))) < 1e-12
+        assert np.max(np.abs(G @ U - U * lam_v)) < 1e-11 * ref[0]

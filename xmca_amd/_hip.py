@@ -37,6 +37,7 @@ SIGNATURES = {
     "xmca_solve": (_c_int, [_vp, _c_int, _c_i64, ctypes.POINTER(_c_i64)]),
     "xmca_get_singular_values": (_c_int, [_vp, _vp, _c_i64]),
     "xmca_get_vectors": (_c_int, [_vp, _c_int, _vp, _c_i64, _c_int]),
+    "xmca_get_eofs": (_c_int, [_vp, _c_int, _vp, _c_i64, _c_i64, _c_int, _vp, _c_int]),
     "xmca_center_field": (_c_int, [_vp, _c_int, _vp, _vp, ctypes.POINTER(_c_i64)]),
     "xmca_compact_field": (_c_int, [_vp, _c_int, _vp, ctypes.POINTER(_c_i64)]),
     "xmca_scale_field": (_c_int, [_vp, _c_int, _vp, _c_int]),
@@ -66,6 +67,7 @@ SIGNATURES = {
                                      ctypes.c_uint64, _c_int, _vp, _vp, _c_i64]),
     "xmca_surrogate": (_c_int, [_vp, _c_i64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _vp]),
     "xmca_get_timings": (_c_int, [_vp, ctypes.c_char_p, _c_int, _vp, _c_int]),
+    "xmca_get_reduction_info": (_c_int, [_vp, ctypes.c_char_p, _c_int]),
     "xmca_reset_timings": (_c_int, [_vp]),
     "xmca_fft": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, _vp, _vp]),
     "xmca_pool_bytes": (_c_int, [_vp, ctypes.POINTER(ctypes.c_int64)]),
@@ -85,7 +87,7 @@ def library_path():
     return _build.LIB
 
 
-ABI_VERSION = 8          # bumped whenever a signature of include/xmca_hip.h changes; checked against xmca_abi_version()
+ABI_VERSION = 9          # bumped whenever a signature of include/xmca_hip.h changes; checked against xmca_abi_version()
 
 
 def load_library():
@@ -279,6 +281,24 @@ class Handle:
         self._check(self._lib.xmca_get_vectors(self._h, side, _ptr(out), n_modes, code))
         return out
 
+    def eofs(self, side, N, m, W, dtype):
+        """(N x q) EOFs of `side` in their final layout: V[:, :m] @ W mixed on the device (W: m x q float64 / complex128), or the
+        first m vectors as they are (W None).  xmca_get_eofs: array.py:615-646 + :676-721 without an N x m pass on the host."""
+        cplx = bool(self._lib.xmca_is_complex(self._h))
+        code = _np_dtype_code(dtype)
+        w_cplx = W is not None and np.iscomplexobj(W)
+        if W is not None:
+            W = np.ascontiguousarray(W, dtype=np.complex128 if w_cplx else np.float64)
+            m, q = W.shape
+        else:
+            q = m
+        if cplx or w_cplx:
+            out = np.empty((N, q), dtype=np.complex64 if code == XMCA_F32 else np.complex128)
+        else:
+            out = np.empty((N, q), dtype=np.float32 if code == XMCA_F32 else np.float64)
+        self._check(self._lib.xmca_get_eofs(self._h, side, _ptr(W), m, q, int(w_cplx), _ptr(out), code))
+        return out
+
     def project(self, side, V, T):
         """U = X~ V (T x m) on the resident field of `side` (the analytic signal when the model is complex);
         float64 / complex128.  MCA._get_U's `fields[k] @ V[k]` (array.py:391)."""
@@ -436,6 +456,14 @@ class Handle:
         return out
 
     # ---- instrumentation ----------------------------------------------------------------------
+    def reduction_info(self):
+        """names of the kernels of the last tridiagonal reduction (xmca_get_reduction_info)"""
+        buf = ctypes.create_string_buffer(4096)
+        n = self._lib.xmca_get_reduction_info(self._h, buf, 4096)
+        if n < 0:
+            self._check(n)
+        return buf.value.decode()
+
     def timings(self):
         names = ctypes.create_string_buffer(4096)
         ms = np.zeros(64)

@@ -639,20 +639,59 @@ class MCA:
             return norm['left'] * norm['right']
         return norm['left'] ** 2
 
+    def _eofs_from_device(self, n, rotated):
+        """(N' x q) array per field in its final memory layout, mixed on the device from the vectors still resident there
+        (`xmca_get_eofs`), or None when they are not (then `_get_V`'s host path is taken).  Same numbers as `_get_V`:
+        `(V sqrt(s)) @ R / norm`, columns ordered by explained variance, then the requested slice (array.py:615-646)."""
+        Vl = getattr(self, '_V', None)
+        if not (isinstance(Vl, _LazyVectors) and Vl._pending == set(self._keys)):
+            return None                                   # (vectors already on the host - or injected by a test: no device needed)
+        dev = self._device()
+        if not dev.holds_result_of(self):
+            return None
+        rotated = rotated and self._analysis['is_rotated']
+        max_mode = self._max_mode(n, rotated)
+        max_mode = self._analysis['rank'] if max_mode is None else min(max_mode, self._analysis['rank'])
+        keep = self._get_slice(n)
+        if max_mode < 1 or len(range(max_mode)[keep]) < 1:
+            return None
+        out = {}
+        for side, k in enumerate(self._keys):
+            n_k = Vl._where[k][1]
+            if rotated:
+                sqrt_svals = np.sqrt(self._get_svals(max_mode))
+                norm = self._get_norm(max_mode, sorted=False)
+                W = ((sqrt_svals[:, None] * self.rotation_matrix()) / norm[k])[:, self._var_idx][:, keep]
+                out[k] = dev.eofs(side, n_k, max_mode, W, np.float64)
+            else:
+                cols = range(max_mode)[keep]
+                if cols.start == 0 and cols.step == 1:
+                    out[k] = dev.eofs(side, n_k, len(cols), None, Vl._dtype)
+                else:
+                    W = np.eye(max_mode)[:, keep]
+                    out[k] = dev.eofs(side, n_k, max_mode, W, Vl._dtype)
+        return out
+
     def _get_eofs(self, n=None, scaling='None', phase_shift=0, rotated=True):
-        V = self._get_V(n, rotated=rotated)
+        V = self._eofs_from_device(n, rotated)
+        if V is None:
+            V = self._get_V(n, rotated=rotated)
         eofs = {}
         for k in self._keys:
             n_modes = V[k].shape[1]
-            full = self._with_nan_columns(k, V[k].T, (n_modes,)).T            # (N, n_modes), NaN at masked points
+            if self._n_variables[k] == V[k].shape[0] and V[k].flags['C_CONTIGUOUS']:
+                full = V[k]                                                   # no masked points: the array is final as it is
+            else:
+                full = np.full((self._n_variables[k], n_modes), np.nan, dtype=V[k].dtype)
+                full[self._no_nan_index[k]] = V[k]                            # (N, n_modes), NaN at masked points
             eofs[k] = full.reshape(self._fields_spatial_shape[k] + (n_modes,))
-            if self._analysis['is_complex']:
+            if self._analysis['is_complex'] and phase_shift != 0:
                 eofs[k] = eofs[k] * cmath.rect(1, phase_shift)
             space_axes = tuple(range(eofs[k].ndim - 1))
             if scaling == 'None':
                 pass
             elif scaling == 'eigen':
-                eofs[k] = eofs[k] * self._get_norm(V['left'].shape[1], sorted=True)[k]
+                eofs[k] = eofs[k] * self._get_norm(V[self._keys[0]].shape[1], sorted=True)[k]
             elif scaling == 'max':
                 eofs[k] = eofs[k] / np.nanmax(abs(eofs[k].real), axis=space_axes)
             elif scaling == 'std':

@@ -107,11 +107,9 @@ void cgemm(hipStream_t st, GemmWorkspace& ws, const TI* Ar, const TI* Ai, int64_
 // one panel: diagonal block + row panel in one launch (chol64.h; the LDS image is dynamic: above 64 KB for complex problems)
 template <bool CPLX>
 static void chol64_launch_panel(hipStream_t st, double* Gr, double* Gi, int64_t ld, int k0, int nb, int rest, double* Dr, double* Di, int* fail) {
-  static const bool attr = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol64_panel_kernel<CPLX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64Lds<CPLX>::bytes());
-    return true;
-  }();
-  (void)attr;
+  // (before EVERY launch: the attribute is per device - a second GPU's first complex panel would otherwise ask for ~85 KB of dynamic
+  //  LDS above the 64 KB default and fail to launch - and two lane threads could race a once-only initialisation; advisor, round 5)
+  XMCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chol64_panel_kernel<CPLX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64Lds<CPLX>::bytes()));
   hipLaunchKernelGGL((chol64_panel_kernel<CPLX>), dim3(std::max(1, ceil_div(rest, 64))), dim3(256), C64Lds<CPLX>::bytes(), st, Gr, Gi, ld, k0, nb,
                      rest, Dr, Di, fail);
 }

@@ -68,6 +68,64 @@ __global__ void pack_rows_kernel(const double* __restrict__ re, const double* __
   }
 }
 
+// EOFs in their final layout (xmca_get_eofs): out[n][c] = sum_m V[m][n] W[m][c] for the mode-major vectors V (planes of TV, rows
+// ld apart; Vi == nullptr: real) and a small mixing matrix W (m x q planes in float64; Wi == nullptr: real).  One thread per grid
+// point n: the reads of a mode are coalesced over n, the q values of a point are written side by side.  The output is complex
+// (interleaved) when V or W is.
+template <typename TV, typename TO>
+__global__ void eof_mix_kernel(const TV* __restrict__ Vr, const TV* __restrict__ Vi, int64_t ld, int64_t N, int m, int q,
+                               const double* __restrict__ Wr, const double* __restrict__ Wi, TO* __restrict__ out) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const bool oc = Vi || Wi;
+  for (int c0 = 0; c0 < q; c0 += 8) {
+    double ar[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ai[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int mm = 0; mm < m; ++mm) {
+      const double vr = (double)Vr[(int64_t)mm * ld + n], vi = Vi ? (double)Vi[(int64_t)mm * ld + n] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = c0 + u < q ? c0 + u : q - 1;
+        const double wr = Wr[mm * q + c], wi = Wi ? Wi[mm * q + c] : 0.0;
+        ar[u] += vr * wr - vi * wi;
+        ai[u] += vr * wi + vi * wr;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = c0 + u;
+      if (c < q) {
+        if (oc) { out[2 * (n * q + c)] = (TO)ar[u]; out[2 * (n * q + c) + 1] = (TO)ai[u]; }
+        else out[n * q + c] = (TO)ar[u];
+      }
+    }
+  }
+}
+// ... and without a mixing matrix: out[n][c] = V[c][n], a 32 x 32 tile at a time through LDS (both sides coalesced)
+template <typename TV, typename TO>
+__global__ __launch_bounds__(256) void eof_transpose_kernel(const TV* __restrict__ Vr, const TV* __restrict__ Vi, int64_t ld, int64_t N, int q,
+                                                           TO* __restrict__ out) {
+  __shared__ double tr[32][33], ti[32][33];
+  const int64_t n0 = (int64_t)blockIdx.x * 32;
+  const int c0 = (int)blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r;
+    const int64_t n = n0 + tx;
+    const bool in = c < q && n < N;
+    tr[r][tx] = in ? (double)Vr[(int64_t)c * ld + n] : 0.0;
+    ti[r][tx] = (in && Vi) ? (double)Vi[(int64_t)c * ld + n] : 0.0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t n = n0 + r;
+    const int c = c0 + tx;
+    if (n < N && c < q) {
+      if (Vi) { out[2 * (n * q + c)] = (TO)tr[tx][r]; out[2 * (n * q + c) + 1] = (TO)ti[tx][r]; }
+      else out[n * q + c] = (TO)tr[tx][r];
+    }
+  }
+}
+
 // X[r][c] *= s[r] (by_row) or s[c]; both planes
 __global__ void scale_kernel(double* __restrict__ re, double* __restrict__ im, int64_t ld, int rows, int cols,
                              const double* __restrict__ s, int by_row, int invert) {

@@ -1369,6 +1369,7 @@ struct TrdWorkspace {
   DevBuf<unsigned int> flags;
   int resident_used = 0;             // 1: the last reduction ran as the persistent resident kernel, 2: it gave up and was repeated
   int stages_used = 0;               // launches of the persistent form in the last reduction (1, or the links of the chain)
+  std::string last_desc;             // the kernels of the last reduction by name (xmca_get_reduction_info; bench.py `roofline.kernel`)
   // hipEvents around the reduction kernel(s) of every call (the dominant kernel of a solve: bench.py `roofline`)
   hipEvent_t ev[2] = {nullptr, nullptr};
   bool ev_pending = false;
@@ -1665,6 +1666,15 @@ inline TrdParams trd_reduce(hipStream_t st, TrdWorkspace& ws, const double* Ar, 
         std::fprintf(stderr, "xmca: trd_resident_kernel: workgroup %d ran out of its spins at column %d of its launch (n = %d, %d launches)\n", dbg[3], dbg[2], n, (int)stages.size());
     }
     ws.stages_used = (int)stages.size();
+    {
+      std::string d = stages.size() > 1 ? "chain of " + std::to_string(stages.size()) + " persistent launches: " : "";
+      for (size_t q = 0; q < stages.size(); ++q) {
+        const TrdStage& sg = stages[q];
+        d += (q ? " -> " : "") + std::string("trd_resident_kernel<") + (cplx ? "complex" : "real") + ",NC=" + std::to_string(sg.nc) + ",RR=" + std::to_string(sg.rr) +
+             (tagged ? ",tagged>" : ",flags>") + " columns [" + std::to_string(sg.j_begin) + "," + std::to_string(sg.j_end) + ")";
+      }
+      ws.last_desc = d;
+    }
     if (prof_file_r) {
       std::vector<unsigned long long> hp((size_t)8 * n);
       XMCA_HIP(hipMemcpy(hp.data(), P.prof, sizeof(unsigned long long) * hp.size(), hipMemcpyDeviceToHost));
@@ -1696,6 +1706,7 @@ inline TrdParams trd_reduce(hipStream_t st, TrdWorkspace& ws, const double* Ar, 
     }
   }
 
+  ws.last_desc = std::string("trd_step_kernel<") + (cplx ? "complex" : "real") + "> x " + std::to_string(n) + " launches (one per column)";
   const size_t lds = trd_step_lds(n, cplx);
   const int slots = ((n + 3) + 1) & ~1;
   const int ns = slots <= 2 * TRD_THREADS ? 2 : slots <= 4 * TRD_THREADS ? 4 : slots <= 8 * TRD_THREADS ? 8 : 16;

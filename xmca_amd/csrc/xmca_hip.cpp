@@ -222,6 +222,39 @@ void get_vectors_impl(xmca_handle* h, int side, void* out, int64_t m) {
   XMCA_HIP(hipStreamSynchronize(h->st));
 }
 
+// EOFs of `side` in the reference's final layout (see xmca_get_eofs): N x q, mixed on the device from the resident mode-major vectors
+template <typename TO>
+void get_eofs_impl(xmca_handle* h, int side, const double* W, int64_t m, int64_t q, bool w_cplx, void* out) {
+  const SolveResult& r = h->res;
+  const int64_t N = r.ldv[side];
+  const bool v_cplx = r.cplx, o_cplx = v_cplx || (W && w_cplx);
+  const size_t n_out = (size_t)N * q * (o_cplx ? 2 : 1);
+  DevBuf<TO> tmp;
+  tmp.ensure(n_out);
+  DevBuf<double> wr, wi, wh;
+  if (W) {
+    const size_t nw = (size_t)m * q;
+    XMCA_HIP(hipMemcpyAsync(wh.ensure(nw * (w_cplx ? 2 : 1)), W, sizeof(double) * nw * (w_cplx ? 2 : 1), hipMemcpyHostToDevice, h->st));
+    if (w_cplx) hipLaunchKernelGGL((split_complex_kernel<double, double>), ew_grid((int64_t)nw), dim3(EW_BLOCK), 0, h->st, wh.get(), wr.ensure(nw), wi.ensure(nw), (int64_t)nw);
+    const double* Wr = w_cplx ? wr.get() : wh.get();
+    const double* Wi = w_cplx ? wi.get() : nullptr;
+    const dim3 grid((unsigned)ceil_div(N, 256));
+    if (r.vt_f32[side])
+      hipLaunchKernelGGL((eof_mix_kernel<float, TO>), grid, dim3(256), 0, h->st, r.Vt32[side].get(), (const float*)nullptr, N, N, (int)m, (int)q, Wr, Wi, tmp.get());
+    else
+      hipLaunchKernelGGL((eof_mix_kernel<double, TO>), grid, dim3(256), 0, h->st, r.Vt[side].r(), r.Vt[side].i(v_cplx), N, N, (int)m, (int)q, Wr, Wi, tmp.get());
+  } else {
+    const dim3 grid((unsigned)ceil_div(N, 32), (unsigned)ceil_div(q, 32));
+    if (r.vt_f32[side])
+      hipLaunchKernelGGL((eof_transpose_kernel<float, TO>), grid, dim3(256), 0, h->st, r.Vt32[side].get(), (const float*)nullptr, N, N, (int)q, tmp.get());
+    else
+      hipLaunchKernelGGL((eof_transpose_kernel<double, TO>), grid, dim3(256), 0, h->st, r.Vt[side].r(), r.Vt[side].i(v_cplx), N, N, (int)q, tmp.get());
+  }
+  XMCA_HIP(hipGetLastError());
+  XMCA_HIP(hipMemcpyAsync(out, tmp.get(), n_out * sizeof(TO), hipMemcpyDeviceToHost, h->st));
+  XMCA_HIP(hipStreamSynchronize(h->st));
+}
+
 // U = X~ V on the resident field of `side` (see xmca_project)
 template <typename TI>
 void project_impl(xmca_handle* h, int side, const void* V, int64_t N, int64_t m, bool v_cplx, void* U_out, int* out_cplx) {
@@ -874,6 +907,17 @@ int xmca_get_vectors(xmca_handle* h, int side, void* out, int64_t n_modes, int d
   API_END(h)
 }
 
+int xmca_get_eofs(xmca_handle* h, int side, const double* W, int64_t m, int64_t q, int w_is_complex, void* out, int dtype) {
+  API_BEGIN(h)
+  XMCA_CHECK(h->solved, XMCA_ERR_STATE, "eofs requested before solve");
+  XMCA_CHECK(side == 0 || side == 1, XMCA_ERR_INVALID, "get_eofs: side must be 0 or 1");
+  XMCA_CHECK(out && q >= 1 && m >= 1 && m <= h->res.n_vec && (W || q == m) && h->res.ldv[side] > 0, XMCA_ERR_INVALID,
+             "get_eofs: more modes requested than were back-projected, or a bad mixing matrix");
+  if (dtype == XMCA_F32) get_eofs_impl<float>(h, side, W, m, q, w_is_complex != 0, out);
+  else get_eofs_impl<double>(h, side, W, m, q, w_is_complex != 0, out);
+  API_END(h)
+}
+
 int xmca_project(xmca_handle* h, int side, const void* V, int64_t N, int64_t m, int is_complex, void* U_out,
                  int* out_is_complex) {
   API_BEGIN(h)
@@ -1249,6 +1293,14 @@ int xmca_surrogate(xmca_handle* h, int64_t n, uint64_t seed, uint32_t run, uint3
   XMCA_HIP(hipMemcpyAsync(out, d.get(), sizeof(double) * n, hipMemcpyDeviceToHost, h->st));
   XMCA_HIP(hipStreamSynchronize(h->st));
   API_END(h)
+}
+
+int xmca_get_reduction_info(xmca_handle* h, char* out, int out_len) {
+  if (!h || !out || out_len < 1) return XMCA_ERR_INVALID;
+  const std::string& d = h->ews.trd.last_desc;
+  std::strncpy(out, d.c_str(), (size_t)out_len - 1);
+  out[out_len - 1] = 0;
+  return (int)d.size();
 }
 
 int xmca_get_timings(xmca_handle* h, char* names, int names_len, double* ms, int max_n) {

@@ -70,27 +70,55 @@ def broadcast_seed(seed, dev=None):
 
 def init_native(dev, rank=None, world=None, id_file=None, timeout=120.0):
     """Native RCCL communicator over the ranks of a launcher WITHOUT torch.distributed: rank 0 writes the 128-byte
-    ncclUniqueId to `id_file` (atomically), the others wait for it, all call ncclCommInitRank.  Returns `_hip.Comm`."""
+    ncclUniqueId to `id_file` (atomically), the others wait for it, all call ncclCommInitRank.  Returns `_hip.Comm`.
+
+    The rendezvous file is keyed per LAUNCH (advisor, round 5: under torchrun the run id defaults to 'none', so a file left by a
+    run that died was picked up - at once - by the next run's ranks, which then hung in ncclCommInitRank on a stale id):
+    `XMCA_COMM_ID_FILE`, else /dev/shm/xmca_comm_id_<uid>_<MASTER_PORT>_<run id>_<restart count>_<launcher pid>.  Readers also
+    reject a file older than their own process (a leftover of an earlier launch with the same key), rank 0 removes any
+    pre-existing file before it publishes, and the file is created exclusively (O_EXCL | O_NOFOLLOW, mode 0600) under a
+    temporary name and renamed into place."""
     from . import _hip
     rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
     world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
     if id_file is None:
-        id_file = os.environ.get("XMCA_COMM_ID_FILE") or "/dev/shm/xmca_comm_id_%s_%s" % (
-            os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", str(os.getppid())))
+        id_file = os.environ.get("XMCA_COMM_ID_FILE") or "/dev/shm/xmca_comm_id_%d_%s_%s_%s_%d" % (
+            os.getuid(), os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"),
+            os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"), os.getppid())
+    started = _process_start_time()
     if rank == 0:
+        try:
+            os.remove(id_file)                    # a leftover with this key is never a live rendezvous: rank 0 has not published yet
+        except OSError:
+            pass
         uid = _hip.comm_unique_id()
         tmp = id_file + ".tmp%d" % os.getpid()
-        with open(tmp, "wb") as f:
+        try:
+            os.remove(tmp)
+        except OSError:
+            pass
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+        with os.fdopen(fd, "wb") as f:
             f.write(uid)
         os.replace(tmp, id_file)
     else:
         t0 = time.time()
-        while not (os.path.exists(id_file) and os.path.getsize(id_file) == _hip.COMM_ID_BYTES):
-            if time.time() - t0 > timeout:
-                raise TimeoutError("no RCCL unique id at %s after %.0f s" % (id_file, timeout))
-            time.sleep(0.01)
-        with open(id_file, "rb") as f:
-            uid = f.read()
+        uid = None
+        while uid is None:
+            try:
+                fd = os.open(id_file, os.O_RDONLY | getattr(os, "O_NOFOLLOW", 0))
+                with os.fdopen(fd, "rb") as f:
+                    st = os.fstat(f.fileno())
+                    data = f.read()
+                # (written by rank 0 of THIS launch: not older than this process, owned by this user)
+                if len(data) == _hip.COMM_ID_BYTES and st.st_mtime >= started - 1.0 and st.st_uid == os.getuid():
+                    uid = data
+            except OSError:
+                pass
+            if uid is None:
+                if time.time() - t0 > timeout:
+                    raise TimeoutError("no fresh RCCL unique id at %s after %.0f s" % (id_file, timeout))
+                time.sleep(0.01)
     comm = _hip.Comm(dev, uid, rank, world)          # collective: returns once every rank has joined
     if rank == 0 and world > 0:
         try:
@@ -98,6 +126,18 @@ def init_native(dev, rank=None, world=None, id_file=None, timeout=120.0):
         except OSError:
             pass
     return comm
+
+
+def _process_start_time():
+    """wall-clock time this process started (seconds since the epoch); falls back to 'now' where /proc is not available"""
+    try:
+        with open("/proc/self/stat") as f:
+            ticks = float(f.read().rsplit(")", 1)[1].split()[19])
+        with open("/proc/uptime") as f:
+            up = float(f.read().split()[0])
+        return time.time() - up + ticks / os.sysconf("SC_CLK_TCK")
+    except Exception:                                             # noqa: BLE001
+        return time.time()
 
 
 def sharded_rule_n(dev, n_runs, *, T, Nx, Ny, n_fields, complexify, rotated, p, power, tol, seed, dtype, n_out, comm=None):
