@@ -428,7 +428,8 @@ def test_bench_py_reports_the_tridiagonal_reduction_as_its_dominant_kernel():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     rf = line["roofline"]
-    assert rf["kernel"].startswith("trd_") and rf["bound"] == "latency"
+    # (the name is the library's own: xmca_get_reduction_info - one persistent launch or the chain of re-packed ones, round 6)
+    assert ("trd_resident_kernel<real,NC=" in rf["kernel"] or rf["kernel"].startswith("trd_step_kernel")) and rf["bound"] == "latency"
     assert abs(rf["flops_per_launch"] - 4.0 / 3.0 * T ** 3) < 1.0
     assert 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert rf["exchange_us_per_column"] > 0 and rf["launches_per_step"] >= 1

@@ -305,13 +305,18 @@ __device__ __forceinline__ void rot_accum_body(double* __restrict__ sm, const do
         }
         __syncthreads();
         if (MODE == 3) {
-          for (int k = wave; k < p; k += 4) {
-            const double xr = Xr[k * ROT_LDP + lane];
-            double a2 = xr * xr;
-            if constexpr (CPLX) { const double xi = Xi[k * ROT_LDP + lane]; a2 += xi * xi; }
-            double a = (n0 + lane < N) ? sqrt(a2) : 0.0;
-            for (int o = 32; o > 0; o >>= 1) a = fmax(a, __shfl_xor(a, o));
-            if (lane == 0 && a > 0.0) atomicMax(&colmax_bits[k], (unsigned long long)__double_as_longlong(a));
+          // running maximum per lane and mode slot (mode k = wave + 4 s); ONE atomic per wave and mode behind the tile loop (round 6:
+          // one per tile and mode - 162 000 atomics on ten words at C5 - took 1.5 ms)
+#pragma unroll
+          for (int s4 = 0; s4 < ROT_PMAX / 4; ++s4) {
+            const int k = wave + 4 * s4;
+            if (k < p) {
+              const double xr = Xr[k * ROT_LDP + lane];
+              double a2 = xr * xr;
+              if constexpr (CPLX) { const double xi = Xi[k * ROT_LDP + lane]; a2 += xi * xi; }
+              const double a = (n0 + lane < N) ? sqrt(a2) : 0.0;
+              accr[s4] = fmax(accr[s4], a);                 // (MODE 3 has no sums: the accumulators carry the maxima)
+            }
           }
           continue;
         }
@@ -359,7 +364,18 @@ __device__ __forceinline__ void rot_accum_body(double* __restrict__ sm, const do
       }
     }
   }
-  if (MODE == 3) return;
+  if (MODE == 3) {
+#pragma unroll
+    for (int s4 = 0; s4 < ROT_PMAX / 4; ++s4) {
+      const int k = wave + 4 * s4;
+      if (k < p) {
+        double a = accr[s4];
+        for (int o = 32; o > 0; o >>= 1) a = fmax(a, __shfl_xor(a, o));
+        if (lane == 0 && a > 0.0) atomicMax(&colmax_bits[k], (unsigned long long)__double_as_longlong(a));
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int sl = 0; sl < MAXE; ++sl) {
     const int e = tid + 256 * sl;
@@ -397,17 +413,28 @@ static inline size_t rot_accum_smem(int p, bool cplx) {
 static inline int rot_max_modes(bool cplx) { return cplx ? 48 : ROT_PMAX; }   // LDS budget of rot_accum_kernel
 
 // out[e] = sum_wg part[wg*pp + e]
-__global__ void rot_reduce_partials_kernel(const double* __restrict__ part_r, const double* __restrict__ part_i, int nwg, int pp,
-                                           double* __restrict__ out_r, double* __restrict__ out_i) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= pp) return;
+// One workgroup per entry (grid = pp): thread t adds the partials t, t + 256, ... in that order, thread 0 then adds the 256 slice
+// sums in order - one fixed summation order (up to 256 partials: the plain sequence 0, 1, 2, ... of rounds 1-5, bit for bit; the
+// 2048-workgroup grids of long fields: 8 dependent loads per thread instead of 2048 - 482 us per call at C5 before).
+__global__ __launch_bounds__(256) void rot_reduce_partials_kernel(const double* __restrict__ part_r, const double* __restrict__ part_i, int nwg, int pp,
+                                                                 double* __restrict__ out_r, double* __restrict__ out_i) {
+  __shared__ double sr_sh[256], si_sh[256];
+  const int e = blockIdx.x, t = threadIdx.x;
   double sr = 0.0, si = 0.0;
-  for (int w = 0; w < nwg; ++w) {
+  for (int w = t; w < nwg; w += 256) {
     sr += part_r[(int64_t)w * pp + e];
     if (part_i) si += part_i[(int64_t)w * pp + e];
   }
-  out_r[e] = sr;
-  if (out_i) out_i[e] = si;
+  sr_sh[t] = sr;
+  si_sh[t] = si;
+  __syncthreads();
+  if (t == 0) {
+    double ar = 0.0, ai = 0.0;
+    const int m = nwg < 256 ? nwg : 256;
+    for (int q = 0; q < m; ++q) { ar += sr_sh[q]; ai += si_sh[q]; }
+    out_r[e] = ar;
+    if (out_i) out_i[e] = ai;
+  }
 }
 
 // c_k = real( sum_{j,l} conj(R[j][k]) A0[j][l] R[l][k] )
@@ -1547,30 +1574,28 @@ __device__ __forceinline__ void varimax_accum_mfma_pt1(double* __restrict__ sm, 
   d4_t gr = {0, 0, 0, 0}, gi = {0, 0, 0, 0};
 
   const int64_t nbatch = (N + ROT_PB - 1) / ROT_PB;
-  for (int64_t bt = blockIdx.x; bt < nbatch; bt += gridDim.x) {
-    const int64_t n0 = bt * ROT_PB;
-    double* Tr = Yr;
-    double* Ti = Yi;
-    if (res_r) {
-      const int64_t bl = (bt - blockIdx.x) / gridDim.x;
-      Tr = res_r + bl * pl;
-      Ti = res_i + bl * pl;
+  // Tiles that do not stay in LDS (long grids: 63 tiles per workgroup and iteration at C5) are PREFETCHED: the loads of the next
+  // PF tiles of this workgroup are in flight - in registers, at most 4 values per thread and tile for p <= 16 - while a tile is
+  // multiplied (round 6; one tile at a time read the planes at 0.4 TB/s: a trip to memory per tile, 207 us per iteration at C5).
+  constexpr int PF = CPLX ? 1 : 8, NV = 4;      // (complex: the kernel is at its 512 registers - one tile ahead)
+  double pfr[PF][NV], pfi[CPLX ? PF : 1][CPLX ? NV : 1];
+  // (issue only: a select on the loaded value here would make the compiler wait for the load at once - out-of-range slots read
+  //  element 0 and are masked when the tile is written to LDS)
+  auto pf_in = [&](const int64_t bt, const int u) {
+    const int e = tid + 256 * u, j = e / ROT_PB, pt = e % ROT_PB;
+    return bt < nbatch && j < p && bt * ROT_PB + pt < N;
+  };
+  auto pf_issue = [&](const int64_t bt, double (&vr)[NV], double* vi) {
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int e = tid + 256 * u, j = e / ROT_PB, pt = e % ROT_PB;
+      const int64_t a = pf_in(bt, u) ? (int64_t)j * N + bt * ROT_PB + pt : 0;
+      vr[u] = Ar[a];
+      if constexpr (CPLX) vi[u] = Ai[a];
     }
-    if (!res_r || !res_ready) {
-      __syncthreads();                    // the staging buffer is no longer read
-      for (int e = tid; e < p * ROT_PB; e += 256) {
-        const int j = e / ROT_PB, pt = e % ROT_PB;
-        const int64_t n = n0 + pt;
-        double vr = 0.0, vi = 0.0;
-        if (n < N) {
-          vr = Ar[(int64_t)j * N + n];
-          if constexpr (CPLX) vi = Ai[(int64_t)j * N + n];
-        }
-        Tr[j * ROT_LDP + pt] = vr;
-        if constexpr (CPLX) Ti[j * ROT_LDP + pt] = vi;
-      }
-      __syncthreads();
-    }
+  };
+  // one 64-point tile staged at (Tr, Ti): Z = A R on this wave's 16 points, W, G += A^H W (everything in registers)
+  auto tile_ops = [&](const double* __restrict__ Tr, const double* __restrict__ Ti, d4_t& g_r, d4_t& g_i) {
     double ar[KS], ai[KS], qa[4], qb[4];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -1602,12 +1627,81 @@ __device__ __forceinline__ void varimax_accum_mfma_pt1(double* __restrict__ sm, 
       // W = (|z|^2 - c_k / N) z     (rotation.py:56-57);  G[j][k] += sum_pt conj(A[pt][j]) W[pt][k], step r = points l4 + 4 r
       const double f = zr[r] * zr[r] + zi[r] * zi[r] - cn;
       const double wr = f * zr[r], wi = f * zi[r];
-      gr = Mfma<double>::mma(qa[r], wr, gr);
+      g_r = Mfma<double>::mma(qa[r], wr, g_r);
       if constexpr (CPLX) {
-        gi = Mfma<double>::mma(qa[r], wi, gi);
-        gr = Mfma<double>::mma(qb[r], wi, gr);      // conj(a) w
-        gi = Mfma<double>::mma(-qb[r], wr, gi);
+        g_i = Mfma<double>::mma(qa[r], wi, g_i);
+        g_r = Mfma<double>::mma(qb[r], wi, g_r);      // conj(a) w
+        g_i = Mfma<double>::mma(-qb[r], wr, g_i);
       }
+    }
+  };
+  const bool streaming = !res_r;
+  if (streaming) {
+    // Two tiles per step, each with its own accumulator: the seven (real) dependent MFMAs of a tile - ~100 cycles each for the one
+    // wave of a SIMD - overlap with the other tile's (round 6: 1.2 us per tile -> see DESIGN.md); the second staging buffer is the
+    // area the general form keeps W in.  A slot beyond the last tile holds zeros: it adds nothing.
+    // (complex: one tile per step - the kernel is at its 512 registers)
+    constexpr int STEP = CPLX ? 1 : 2;
+    static_assert(PF % STEP == 0, "tiles are processed in pairs");
+    double* T2r = sm;
+    double* T2i = sm + 2 * pl + pp + ROT_PB;
+    d4_t gr2 = {0, 0, 0, 0}, gi2 = {0, 0, 0, 0};
+#pragma unroll
+    for (int d = 0; d < PF; ++d) pf_issue((int64_t)blockIdx.x + (int64_t)d * gridDim.x, pfr[d], CPLX ? pfi[d] : nullptr);
+    for (int64_t bt0 = blockIdx.x; bt0 < nbatch; bt0 += (int64_t)PF * gridDim.x) {
+#pragma unroll
+      for (int d = 0; d < PF; d += STEP) {
+        const int64_t bt = bt0 + (int64_t)d * gridDim.x, btb = bt + gridDim.x;
+        constexpr int D2 = STEP - 1;        // (index offset of the pair's second slot)
+        if (bt >= nbatch) break;
+        __syncthreads();                    // the staging buffers are no longer read
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+          const int e = tid + 256 * u, j = e / ROT_PB, pt = e % ROT_PB;
+          if (j < p) {
+            const bool ina = pf_in(bt, u);
+            Yr[j * ROT_LDP + pt] = ina ? pfr[d][u] : 0.0;
+            if constexpr (CPLX) Yi[j * ROT_LDP + pt] = ina ? pfi[d][u] : 0.0;
+            if constexpr (STEP == 2) {
+              const bool inb = pf_in(btb, u);
+              T2r[j * ROT_LDP + pt] = inb ? pfr[d + D2][u] : 0.0;
+              if constexpr (CPLX) T2i[j * ROT_LDP + pt] = inb ? pfi[d + D2][u] : 0.0;
+            }
+          }
+        }
+        pf_issue(bt + (int64_t)PF * gridDim.x, pfr[d], CPLX ? pfi[d] : nullptr);            // (these slots' next tiles, PF tiles ahead)
+        if constexpr (STEP == 2) pf_issue(btb + (int64_t)PF * gridDim.x, pfr[d + D2], CPLX ? pfi[d + D2] : nullptr);
+        __syncthreads();
+        tile_ops(Yr, Yi, gr, gi);
+        if constexpr (STEP == 2) tile_ops(T2r, T2i, gr2, gi2);
+      }
+    }
+    if constexpr (STEP == 2) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { gr[r] += gr2[r]; gi[r] += gi2[r]; }
+    }
+  } else {
+    for (int64_t bt = blockIdx.x; bt < nbatch; bt += gridDim.x) {
+      const int64_t n0 = bt * ROT_PB;
+      const int64_t bl = (bt - blockIdx.x) / gridDim.x;
+      double* Tr = res_r + bl * pl;
+      double* Ti = res_i + bl * pl;
+      if (!res_ready) {
+        __syncthreads();
+        for (int e = tid; e < p * ROT_PB; e += 256) {
+          const int j = e / ROT_PB, pt = e % ROT_PB;
+          const int64_t n = n0 + pt;
+          double vr = 0.0, vi = 0.0;
+          if (n < N) {
+            vr = Ar[(int64_t)j * N + n];
+            if constexpr (CPLX) vi = Ai[(int64_t)j * N + n];
+          }
+          Tr[j * ROT_LDP + pt] = vr;
+          if constexpr (CPLX) Ti[j * ROT_LDP + pt] = vi;
+        }
+        __syncthreads();
+      }
+      tile_ops(Tr, Ti, gr, gi);
     }
   }
   __syncthreads();      // the tiles are no longer read: the scratch below may overlap them

@@ -1299,7 +1299,8 @@ struct RotationDevice {
   int64_t N = 0, Nleft = 0;
   int p = 0;
   bool cplx = false;
-  int nwg = 0;
+  int nwg = 0;            // grid of the Varimax kernels (persistent: one workgroup per CU at most)
+  int nacc = 0;           // grid of the one-pass accumulation kernels (Gram, column maxima, Promax fits): sized by N
 };
 
 class Rotator {
@@ -1317,10 +1318,14 @@ class Rotator {
   // summed in two stages whose cost does not grow with the grid (varimax_persistent_kernel): up to one workgroup per CU.
   // Few modes: the all-to-all reduction and the exchange dominate - flat between 40 and 128 workgroups, slower beyond.
   static bool wide_grid(int p, bool cplx) { return (size_t)p * p * (cplx ? 2 : 1) >= 512; }
-  static int pick_nwg(int64_t N, bool wide = false) {
+  // Long grids (more than 1024 tiles of 64 points: the 0.25-degree global grid of C5 has 16 200): the passes are streaming
+  // kernels - the persistent Varimax loop takes one workgroup on every CU (two-stage sum of the partials) and prefetches its
+  // tiles, the one-pass kernels take 8 workgroups per CU (128 workgroups with one tile in flight each read
+  // the 83 MB of planes at 0.4 TB/s).  Up to 1024 tiles everything is as it was (same grids, same bits).
+  static bool long_grid(int64_t N) { return (N + ROT_PB - 1) / ROT_PB > 1024; }
+  static int pick_nwg(int64_t N, bool wide = false, int cap_override = 0) {
     const int64_t nb = (N + ROT_PB - 1) / ROT_PB;
-    constexpr int cap_env = 0;
-    const int cap = cap_env > 0 ? cap_env : (wide ? 256 : 128);
+    const int cap = cap_override > 0 ? cap_override : ((wide || long_grid(N)) ? 256 : 128);
     // equal shares: with 157 tiles and a cap of 128 workgroups, 79 workgroups of 2 tiles beat 128 of 1-2
     const int64_t per = (nb + cap - 1) / cap;
     return (int)std::max<int64_t>(1, (nb + per - 1) / per);
@@ -1331,13 +1336,14 @@ class Rotator {
     const size_t smem = rot_accum_smem(d.p, CPLX);
     auto kern = rot_accum_kernel<CPLX, MODE, SEL>;
     XMCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(kern, dim3(d.nwg), dim3(256), smem, st, d.A.r(), d.A.i(CPLX), d.h.get(), d.N, d.Nleft, d.p, d.R.r(),
+    const int grid = MODE == 0 ? d.nwg : d.nacc;       // (MODE 0: the partials go to the step kernel, which adds up d.nwg of them)
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, d.A.r(), d.A.i(CPLX), d.h.get(), d.N, d.Nleft, d.p, d.R.r(),
                        d.R.i(CPLX), d.cvec.get(), d.colmax.get(), power, d.state.get(), d.part_r.get(),
                        CPLX ? d.part_i.get() : nullptr, reinterpret_cast<unsigned long long*>(d.colmax.get()));
     XMCA_HIP(hipGetLastError());
     if (MODE != 0 && MODE != 3) {
-      hipLaunchKernelGGL(rot_reduce_partials_kernel, dim3(ceil_div(d.p * d.p, 256)), dim3(256), 0, st, d.part_r.get(),
-                         CPLX ? d.part_i.get() : nullptr, d.nwg, d.p * d.p, out_r, CPLX ? out_i : nullptr);
+      hipLaunchKernelGGL(rot_reduce_partials_kernel, dim3(d.p * d.p), dim3(256), 0, st, d.part_r.get(),
+                         CPLX ? d.part_i.get() : nullptr, grid, d.p * d.p, out_r, CPLX ? out_i : nullptr);
       XMCA_HIP(hipGetLastError());
     }
   }
@@ -1348,6 +1354,7 @@ class Rotator {
                "rotate: n_rot = " + std::to_string(p) + " needs the GEMM-based path (no workspace given)");
     d.N = N; d.Nleft = Nleft; d.p = p; d.cplx = cplx;
     d.nwg = pick_nwg(N, wide_grid(p, cplx));
+    d.nacc = long_grid(N) ? pick_nwg(N, false, 2048) : d.nwg;
     d.A.ensure((size_t)p * N, cplx);
     d.h.ensure((size_t)N);
     d.R.ensure((size_t)p * p, cplx);
@@ -1356,8 +1363,8 @@ class Rotator {
     d.acc.ensure((size_t)p * p, cplx);
     d.cvec.ensure((size_t)p);
     d.state.ensure(ROT_STATE_N);
-    d.part_r.ensure((size_t)d.nwg * p * p);
-    if (cplx) d.part_i.ensure((size_t)d.nwg * p * p);
+    d.part_r.ensure((size_t)std::max(d.nwg, d.nacc) * p * p);
+    if (cplx) d.part_i.ensure((size_t)std::max(d.nwg, d.nacc) * p * p);
     d.colmax.ensure((size_t)p);
     if (!d.counter.get()) { d.counter.ensure(1); XMCA_HIP(hipMemsetAsync(d.counter.get(), 0, sizeof(unsigned int), st)); }
   }
@@ -1411,7 +1418,7 @@ class Rotator {
       if (CPLX) d.ppart_i.ensure((size_t)2 * d.nwg * p * p);
       XMCA_HIP(hipMemsetAsync(d.pflags.get(), 0, sizeof(unsigned int) * 2 * d.nwg, st));
       // two-stage sum of the partials when every workgroup would otherwise read more than ~32k doubles (XMCA_ROT_TWO_STAGE=0 / 1 forces)
-      const bool rot_two_stage = [&] { const char* e = std::getenv("XMCA_ROT_TWO_STAGE"); return e ? e[0] != '0' : (size_t)d.nwg * p * p * (CPLX ? 2 : 1) > 32768; }();
+      const bool rot_two_stage = [&] { const char* e = std::getenv("XMCA_ROT_TWO_STAGE"); return e ? e[0] != '0' : ((size_t)d.nwg * p * p * (CPLX ? 2 : 1) > 32768 || (long_grid(d.N) && d.nwg > 128)); }();
       constexpr int rot_poll_delay = 0;     // (a delayed first poll, the lever of the tridiagonal reduction, has no measurable effect here)
       XMCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(varimax_persistent_kernel<CPLX>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_smem));
