@@ -109,9 +109,9 @@ def csrc_hash():
     return hh.hexdigest()[:16]
 
 
-PMC_FILE = os.path.join("profiles", "r05_pmc_c2.json")                 # counter passes of the C2 step (scripts/r05_profiles.sh)
-PMC_GRAM_C2 = os.path.join("profiles", "r05_pmc_gram_c2.json")         # ... of the Gram product alone (scripts/gram_only.py c2)
-PMC_GRAM_C5 = os.path.join("profiles", "r05_pmc_gram_c5.json")         # ... and at C5
+PMC_FILE = os.path.join("profiles", "r06_pmc_c2.json")                 # counter passes of the C2 step (scripts/r06_profiles.sh)
+PMC_GRAM_C2 = os.path.join("profiles", "r06_pmc_gram_c2.json")         # ... of the Gram product alone (scripts/gram_only.py c2)
+PMC_GRAM_C5 = os.path.join("profiles", "r06_pmc_gram_c5.json")         # ... and at C5
 
 
 def pmc_traffic(kernel, same_workload, pmc_file=None):
@@ -333,9 +333,12 @@ def main():
                     "bound": "latency", "achieved": tf, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / F64_MFMA_PEAK_TF,
                     "note": "useful flops (4/3) T^3 of float64 vector FMAs against the 78.6 TF float64 peak (vector = matrix "
                             "peak on MI355X); latency-bound by design: T dependent columns, each one exchange across the chip",
-                    "traffic": pmc_traffic("trd_resident_kernel", (T, N) == (2920, 10000) and resident),
+                    # (a reduction is a chain of launches: per-launch mean of the PMC passes x the links of the chain)
+                    "traffic": (lambda t, k: None if t is None else t * k)(pmc_traffic("trd_resident_kernel", (T, N) == (2920, 10000) and resident),
+                                                                          max(1, h.reduction_info().count("trd_resident_kernel<"))),
+                    "launches_in_chain": max(1, h.reduction_info().count("trd_resident_kernel<")),
                     "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at the default workload, "
-                                      "gfx950-corrected, bytes per launch: %s (scripts/r05_profiles.sh), stamped with the hash "
+                                      "gfx950-corrected, bytes per launch: %s (scripts/r06_profiles.sh), stamped with the hash "
                                       "of xmca_amd/csrc; null when the sources differ or for any other workload" % PMC_FILE,
                     "flops_per_launch": flops_trd, "avg_launch_ms": ms_trd, "launches_per_step": trd_calls / args.steps,
                     "share_of_step": trd_ms / args.steps / ms_per_step, "exchange_us_per_column": 1e3 * ms_trd / T,
@@ -516,6 +519,33 @@ def main():
                                     "traffic_source": "rocprofv3 --pmc passes of scripts/gram_only.py c5, bytes per launch: %s" % PMC_GRAM_C5,
                                     "flops_per_launch": g5["flops"], "avg_launch_ms": g5["kernel_ms"],
                                     "product_ms_incl_reduction": g5["avg_ms"], "algorithmic_bytes": 4.0 * T5 * N5 + 8.0 * T5 * T5}
+            # ---- ... and the rotation at that grid size: Varimax / Promax of 10 modes on N = 1 036 800 points.  A
+            # Varimax iteration is ONE pass over the p x N float64 planes (83 MB: HBM / Infinity-Cache bound, rotation.py:54-60).
+            try:
+                p5 = args.n_rot
+                L5 = (0.2 * rng5.standard_normal((N5, p5), dtype=np.float32)).astype(np.float64)
+                w5 = N5 // p5
+                for j in range(p5):
+                    L5[j * w5:(j + 1) * w5, j] += np.hanning(w5) * (3 - 0.1 * j)
+                Q5, _ = np.linalg.qr(rng5.standard_normal((p5, p5)))
+                L5 = L5 @ Q5
+                h5.rotate_loadings(L5, n_left=N5, power=args.power)        # (first use: workspaces)
+                h5.reset_timings()
+                o5 = h5.rotate_loadings(L5, n_left=N5, power=args.power)
+                t5 = h5.timings()
+                us_it = 1e3 * t5.get("varimax", 0.0) / max(o5["n_iter"], 1)
+                gbs = 8.0 * p5 * N5 / (us_it * 1e-6) / 1e9 if us_it > 0 else 0.0
+                extra["roofline_rotate_c5"] = {
+                    "kernel": "varimax_persistent_kernel<real> (whole Varimax loop in one launch; per iteration one pass over the %d x %d "
+                              "float64 loading planes, prefetched 64-point tiles, MFMA accumulation, two-stage sum of 256 partials)" % (p5, N5),
+                    "bound": "hbm", "achieved": gbs, "peak": 6300.0, "unit": "GB/s", "frac": gbs / 6300.0,
+                    "note": "peak = achievable HBM rate (MI355X_MICROARCH.md); the 83 MB of planes also fit the Infinity Cache; `varimax_ms` "
+                            "includes the Gram pass and the set-up of the loop",
+                    "varimax_ms": t5.get("varimax"), "promax_ms": t5.get("promax"), "iterations": int(o5["n_iter"]),
+                    "us_per_iteration": us_it, "algorithmic_bytes_per_iteration": 8.0 * p5 * N5}
+                del L5
+            except Exception as e:                                # noqa: BLE001
+                extra["roofline_rotate_c5"] = {"error": repr(e)[:300]}
             del h5
         except Exception as e:                                    # noqa: BLE001  (reported, never fatal for the headline)
             extra["roofline_c5"] = {"error": repr(e)[:300]}
