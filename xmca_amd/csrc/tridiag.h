@@ -1473,6 +1473,22 @@ inline int trd_stage_nc(int n, bool cplx) {
 }
 // rows per wave: 256 workgroups x 4 waves x RR rows hold the block (complex: 2 at most - the largest problems stream their first rows)
 inline int trd_stage_rr(int nc, bool cplx) { return cplx ? (nc <= 8 ? 1 : 2) : (nc + 7) / 8; }
+// ... inside several surrogate lanes (rule_n / bootstrapping) the LATE links of a chain are PACKED: more rows per wave, fewer
+// workgroups - a reduction holds its CUs with one 512-register wave per SIMD, nothing of another lane fits beside it, so the CUs a
+// link does not take are what the other lane's kernels run on (round 6).  The arithmetic of a row does not depend on its owner:
+// same bits.  XMCA_TRD_PACK=0 / 1 forces either form everywhere (experiments).
+// Measured (C4, two lanes, ms per surrogate / the reduction alone): unpacked 42.2 / 18.9, rows x 1.5-2 (below) 40.9 / 20.2, rows x 4 in
+// the last two links 41.5 / 22.7; real problems (C2-shaped EOF surrogates) lose 2 % with packing and keep the plain chain.
+inline int trd_stage_rr_packed(int nc, bool cplx) {
+  if (!cplx) return trd_stage_rr(nc, cplx);
+  if (nc == 12) return 3;
+  if (nc == 8 || nc == 4) return 2;
+  return trd_stage_rr(nc, cplx);
+}
+inline bool trd_pack_lanes() {
+  const char* e = std::getenv("XMCA_TRD_PACK");
+  return e ? e[0] != '0' : in_surrogate_lanes();
+}
 inline std::vector<TrdStage> trd_plan(int n, bool cplx, int nc) {
   std::vector<TrdStage> st;
   if (nc <= 0) return st;
@@ -1505,7 +1521,7 @@ inline std::vector<TrdStage> trd_plan(int n, bool cplx, int nc) {
     TrdStage sg{};
     sg.col0 = begin;
     sg.nc = (q == 0 && !(chain && tagged)) ? nc : trd_stage_nc(n - begin, cplx);   // (the tagged chain also STARTS in the smallest instantiation that fits)
-    sg.rr = trd_stage_rr(sg.nc, cplx);
+    sg.rr = (q > 0 && chain && tagged && trd_pack_lanes()) ? trd_stage_rr_packed(sg.nc, cplx) : trd_stage_rr(sg.nc, cplx);
     sg.j_begin = begin;
     sg.j_end = end;
     st.push_back(sg);
@@ -1594,13 +1610,13 @@ inline TrdParams trd_reduce(hipStream_t st, TrdWorkspace& ws, const double* Ar, 
     if (tagged) hipLaunchKernelGGL(trd_prefill_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, P.Ar, P.Ai, n, S.xch);
     S.give_up = reinterpret_cast<int*>(ws.flags.get() + TRD_MAX_WGS);
     using ResFn = void (*)(TrdParams, TrdSync, int);
-    auto pick = [&](int snc) -> ResFn {
+    auto pick = [&](int snc, int srr) -> ResFn {
       if (tagged) {
         if (cplx) {
           switch (snc) {
-            case 4: return trd_resident_kernel<true, 4, 1, true>;
-            case 8: return trd_resident_kernel<true, 8, 1, true>;
-            case 12: return trd_resident_kernel<true, 12, 2, true>;
+            case 4: return srr == 2 ? trd_resident_kernel<true, 4, 2, true> : trd_resident_kernel<true, 4, 1, true>;
+            case 8: return srr == 2 ? trd_resident_kernel<true, 8, 2, true> : trd_resident_kernel<true, 8, 1, true>;
+            case 12: return srr == 3 ? trd_resident_kernel<true, 12, 3, true> : trd_resident_kernel<true, 12, 2, true>;
             case 16: return trd_resident_kernel<true, 16, 2, true>;
             default: return trd_resident_kernel<true, 20, 2, true>;
           }
@@ -1652,7 +1668,7 @@ inline TrdParams trd_reduce(hipStream_t st, TrdWorkspace& ws, const double* Ar, 
         const int wgs = std::max(1, std::min(std::min(n_cus, TRD_MAX_WGS), ceil_div(ns, (TRD_RES_THREADS / 64) * sg.rr)));
         const int first_res = std::max(0, ns - wgs * (TRD_RES_THREADS / 64) * sg.rr);
         const size_t lds = (size_t)sg.nc * 128 * 3 * (cplx ? 2 : 1) * sizeof(double);
-        ResFn fn = pick(sg.nc);
+        ResFn fn = pick(sg.nc, sg.rr);
         XMCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         hipLaunchKernelGGL(fn, dim3(wgs), dim3(TRD_RES_THREADS), lds, st, Pq, Sq, first_res);
       }
