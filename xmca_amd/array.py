@@ -22,6 +22,16 @@ from .tools.array import (block_bootstrap, get_nan_cols, has_nan_time_steps, pea
 _SCALINGS_MSG = ('The scaling option {:} is not valid. Please choose one of the following: None, eigen, std, max')
 
 
+def _two_sided_p(r, n_obs):
+    """Two-sided p-value of a Pearson correlation under the exact null distribution, as tools/array.py:86-88:
+    `2 * scipy.stats.beta(n/2 - 1, n/2 - 1, loc=-1, scale=2).cdf(-abs(r))` = 2 I_{(1-|r|)/2}(n/2 - 1, n/2 - 1): the same regularised
+    incomplete beta function (bit for bit) without the frozen distribution's argument handling.  The function itself is what
+    `homogeneous_patterns` costs on the host (18 of 21.7 ms at C2 for 10^5 values; it holds the GIL, so threads do not help)."""
+    import scipy.special
+    a = n_obs / 2 - 1
+    return 2 * scipy.special.betainc(a, a, (1.0 - np.abs(np.asarray(r, dtype=np.float64))) / 2)
+
+
 class _LazyVectors(dict):
     """`MCA._V` after solve(): (N', rank) singular vectors per field, fetched from the device when first read.  `head`
     fetches only the leading modes while the full array has not been asked for."""
@@ -845,7 +855,6 @@ class MCA:
             self._upload_serial += 1
             self._upload_fields(dev)
         n_obs = self._n_observations['left']
-        dist = scipy.stats.beta(n_obs / 2 - 1, n_obs / 2 - 1, loc=-1, scale=2)
         rvals, pvals = {}, {}
         for side, k in enumerate(self._keys):
             try:
@@ -854,7 +863,7 @@ class MCA:
                 raise KeyError('Key not found. Two fields needed for heterogenous maps.')
             r = dev.correlate(side, y, self._fields_store[k].shape[1])
             r = r.astype(np.result_type(self._fields_store[k].real.dtype, y.dtype), copy=False)
-            p = 2 * dist.cdf(-abs(r))
+            p = _two_sided_p(r, n_obs)
             for src, dst in ((r, rvals), (p, pvals)):
                 full = self._with_nan_columns(k, src.T, (src.shape[1],)).T
                 dst[k] = full.reshape(self._fields_spatial_shape[k] + (src.shape[1],))
