@@ -215,6 +215,14 @@ typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
 // elements: cvt_pk, two unpacks (shift / AND), one packed subtraction - twice - and a last cvt_pk: nine instructions.
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 static __device__ __forceinline__ void gemm_split3(const f4_t& x0, const f4_t& x1, u4_t& h, u4_t& m, u4_t& l) {
+#ifdef XMCA_X3_NOSPLIT_EXPERIMENT
+  // (experiment, WRONG numbers: the three "pieces" are bit patterns of the raw floats - the k-loop without the VALU split, i.e. what
+  //  pre-split bfloat16 planes could reach at best with this tile and pipeline; profiles/r06_bf16_presplit_gate.txt)
+  h = __builtin_bit_cast(u4_t, x0);
+  m = __builtin_bit_cast(u4_t, x1);
+  l = h ^ m;
+  return;
+#endif
   const f2_t x[4] = {f2_t{x0[0], x0[1]}, f2_t{x0[2], x0[3]}, f2_t{x1[0], x1[1]}, f2_t{x1[2], x1[3]}};
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
