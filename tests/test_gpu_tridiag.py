@@ -246,3 +246,26 @@ def test_chain_of_repacked_launches_gives_the_bits_of_one_launch(hip, monkeypatc
         assert np.max(np.abs(lam_v - ref)) < 1e-13 * ref[0]
         assert np.max(np.abs(U.conj().T @ U - np.eye(n))) < 1e-12
         assert np.max(np.abs(G @ U - U * lam_v)) < 1e-11 * ref[0]
+
+
+@pytest.mark.parametrize("n,cplx", [(513, False), (513, True), (1025, True), (1537, False), (2049, True), (2305, False), (2560, True),
+                                    (2561, False), (3072, False)])
+def test_chain_at_the_instantiation_boundaries(hip, monkeypatch, n, cplx):
+    """Orders just above / at every capacity of the chain's instantiations (512, 1024, ... columns; complex 2560 and real 3072 are
+    the largest resident orders): the number of links follows the order, the eigenvalues are those of one launch bit for bit and
+    LAPACK's to 1e-13 (scripts/chain_boundary_sweep.py runs the full list)."""
+    rng = np.random.default_rng(n + cplx)
+    X = rng.standard_normal((n, n + 50))
+    if cplx:
+        X = X + 1j * rng.standard_normal((n, n + 50))
+    G = X @ X.conj().T
+    monkeypatch.setenv("XMCA_TRD_CHAIN", "1")
+    lam, _ = hip.eigh(G, vectors=False)
+    links = hip.reduction_info().count("trd_resident_kernel<")
+    assert links == -(-n // 512), hip.reduction_info()
+    monkeypatch.setenv("XMCA_TRD_CHAIN", "0")
+    one, _ = hip.eigh(G, vectors=False)
+    assert hip.reduction_info().count("trd_resident_kernel<") == 1
+    assert np.array_equal(lam, one)
+    ref = np.linalg.eigvalsh(G)[::-1]
+    assert np.max(np.abs(lam - ref)) < 1e-13 * ref[0]
