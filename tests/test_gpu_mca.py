@@ -789,3 +789,28 @@ def test_eofs_assembled_on_the_device_equal_the_host_path(name, cplx, rot):
             # (float32 models: the host path mixes the vectors as fetched - rounded to float32 -, the device the resident ones)
             tol = 2e-6 if m._V._dtype == np.float32 else 1e-12
             assert np.max(np.abs(f[k][ok] - slow[k][ok])) <= tol * max(np.max(np.abs(slow[k][ok])), 1e-300), (kw, k)
+
+
+def test_bootstrapping_and_rule_n_through_a_process_group_equal_the_plain_calls():
+    """Round 6: `bootstrapping` shards its replicates over the ranks of a torch.distributed job like `rule_n` (dist.sharded_bootstrap:
+    rank 0's composed row indices are broadcast, every rank runs its block on its GPU, ONE all_gather with a status row per rank).
+    A one-rank gloo group in a subprocess - all a one-GPU box allows - takes exactly that path on the real device: the numbers are
+    those of the plain calls (xmca/array.py:1935-1947, :1753-1769)."""
+    import subprocess
+    import sys
+    REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, os, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'));"
+            "from golden_inputs import make_input; from xmca_amd.array import MCA;"
+            "f = make_input('wide_both'); m = MCA(*f); m.solve(complexify=True); m.rotate(4, 2);"
+            "np.random.seed(5); b0 = m.bootstrapping(4, n_modes=3, on_left=True, on_right=True, block_size=2); r0 = m.rule_n(5, seed=9);"
+            "import torch.distributed as td; os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = sys.argv[1];"
+            "td.init_process_group('gloo', rank=0, world_size=1);"
+            "np.random.seed(5); b1 = m.bootstrapping(4, n_modes=3, on_left=True, on_right=True, block_size=2); r1 = m.rule_n(5, seed=9);"
+            "td.destroy_process_group();"
+            "print('EQUAL', bool(np.array_equal(b0, b1)), bool(np.array_equal(r0, r1)), b0.shape, r0.shape)" % (REPO, REPO))
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    r = subprocess.run([sys.executable, "-c", code, str(port)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("EQUAL")][-1]
+    assert line.split()[1] == "True" and line.split()[2] == "True", line
