@@ -359,6 +359,20 @@ def main():
     extra = {}
     if stages.get("varimax") and out.get("n_iter"):
         extra["varimax_us_per_iteration"] = 1e3 * stages["varimax"] / out["n_iter"]
+        # the second kernel of the step (since the chained reduction of round 6 the LARGEST single launch: the rocprof summary lists it
+        # first): one persistent launch for the whole Varimax loop (rotation.py:52-64), per iteration one pass over the loadings, one
+        # all-to-all exchange of the workgroups' p x p partials and the polar factor of their sum - latency-bound like the reduction
+        p_, it_ = args.n_rot, int(out["n_iter"])
+        fl_it = 4.0 * N * p_ * p_ + 10.0 * N * p_
+        extra["roofline_varimax"] = {
+            "kernel": "varimax_persistent_kernel<real> (whole loop in ONE launch; loadings resident in LDS, partial G exchanged write-through + "
+                      "epoch flags, polar factor by scaled Newton-Schulz in one wave on MFMA accumulator-layout registers)",
+            "bound": "latency", "achieved": fl_it * it_ / (stages["varimax"] * 1e-3) / 1e12, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s",
+            "frac": fl_it * it_ / (stages["varimax"] * 1e-3) / 1e12 / F64_MFMA_PEAK_TF,
+            "note": "useful flops 4 N p^2 + 10 N p per iteration (SURVEY 8d); bound by one chip-wide exchange + a p x p polar decomposition per "
+                    "iteration, not by flops or bytes: see us_per_iteration",
+            "iterations": it_, "us_per_iteration": 1e3 * stages["varimax"] / it_, "stage_ms": stages["varimax"],
+            "share_of_step": stages["varimax"] / ms_per_step, "flops_per_iteration": fl_it, "traffic": None}
     # cheap self-check of the timed result (full parity against the oracle is in cpu_baseline/parity and tests/)
     Vt = h.vectors(0, args.n_rot, N, X.dtype)
     proj = X @ Vt.T
