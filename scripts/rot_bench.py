@@ -6,7 +6,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from xmca_amd import _hip
 h = _hip.Handle(0)
 rng = np.random.default_rng(0)
-for name, N, p, cplx, power in [("C2-like", 10000, 10, False, 1), ("C3-like", 35000, 20, True, 4)]:
+CASES = [("C2-like", 10000, 10, False, 1), ("C3-like", 35000, 20, True, 4), ("C5-like", 1036800, 10, False, 1)]
+if len(sys.argv) > 1:
+    CASES = [c for c in CASES if c[0] in sys.argv[1:]]
+for name, N, p, cplx, power in CASES:
     L = 0.2 * rng.standard_normal((N, p))
     w = N // p
     for j in range(p):

@@ -1577,23 +1577,32 @@ __device__ __forceinline__ void varimax_accum_mfma_pt1(double* __restrict__ sm, 
   // Tiles that do not stay in LDS (long grids: 63 tiles per workgroup and iteration at C5) are PREFETCHED: the loads of the next
   // PF tiles of this workgroup are in flight - in registers, at most 4 values per thread and tile for p <= 16 - while a tile is
   // multiplied (round 6; one tile at a time read the planes at 0.4 TB/s: a trip to memory per tile, 207 us per iteration at C5).
-  constexpr int PF = CPLX ? 1 : 8, NV = 4;      // (complex: the kernel is at its 512 registers - one tile ahead)
-  double pfr[PF][NV], pfi[CPLX ? PF : 1][CPLX ? NV : 1];
-  // (issue only: a select on the loaded value here would make the compiler wait for the load at once - out-of-range slots read
-  //  element 0 and are masked when the tile is written to LDS)
-  auto pf_in = [&](const int64_t bt, const int u) {
-    const int e = tid + 256 * u, j = e / ROT_PB, pt = e % ROT_PB;
-    return bt < nbatch && j < p && bt * ROT_PB + pt < N;
+  // Each thread fetches PAIRS of neighbouring points (16-byte loads: half the requests of 8-byte ones - the accumulation of a long
+  // grid is bound by the number of requests in flight, 2.1 TB/s with 8-byte loads): pair e = tid + 256 u of a tile = mode e / 32,
+  // points 2 (e % 32), + 1.
+  constexpr int PF = CPLX ? 1 : 8, NV = 2;      // (complex: the kernel is at its 512 registers - one tile ahead)
+  double2 pfr[PF][NV], pfi[CPLX ? PF : 1][CPLX ? NV : 1];
+  // (issue only: a select on the loaded value here would make the compiler wait for the load at once - out-of-range pairs read
+  //  a valid pair and are masked when the tile is written to LDS.  0: both points inside, 1: only the first (the pair then read is
+  //  (N - 2, N - 1): the point is its SECOND element), 2: none)
+  auto pf_state = [&](const int64_t bt, const int u) {
+    const int e = tid + 256 * u, j = e / (ROT_PB / 2), pt = 2 * (e % (ROT_PB / 2));
+    const int64_t n = bt * ROT_PB + pt;
+    if (!(bt < nbatch && j < p) || n >= N) return 2;
+    return n + 1 < N ? 0 : 1;
   };
-  auto pf_issue = [&](const int64_t bt, double (&vr)[NV], double* vi) {
+  auto pf_issue = [&](const int64_t bt, double2 (&vr)[NV], double2* vi) {
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
-      const int e = tid + 256 * u, j = e / ROT_PB, pt = e % ROT_PB;
-      const int64_t a = pf_in(bt, u) ? (int64_t)j * N + bt * ROT_PB + pt : 0;
-      vr[u] = Ar[a];
-      if constexpr (CPLX) vi[u] = Ai[a];
+      const int e = tid + 256 * u, j = e / (ROT_PB / 2), pt = 2 * (e % (ROT_PB / 2));
+      const int st8 = pf_state(bt, u);
+      const int64_t a = st8 == 0 ? (int64_t)j * N + bt * ROT_PB + pt : (st8 == 1 && N >= 2 ? (int64_t)j * N + N - 2 : 0);
+      vr[u] = *reinterpret_cast<const double2*>(Ar + a);
+      if constexpr (CPLX) vi[u] = *reinterpret_cast<const double2*>(Ai + a);
     }
   };
+  auto pf_first = [&](const double2 v, const int st8) { return st8 == 0 ? v.x : (st8 == 1 ? v.y : 0.0); };
+  auto pf_second = [&](const double2 v, const int st8) { return st8 == 0 ? v.y : 0.0; };
   // one 64-point tile staged at (Tr, Ti): Z = A R on this wave's 16 points, W, G += A^H W (everything in registers)
   auto tile_ops = [&](const double* __restrict__ Tr, const double* __restrict__ Ti, d4_t& g_r, d4_t& g_i) {
     double ar[KS], ai[KS], qa[4], qb[4];
@@ -1657,15 +1666,23 @@ __device__ __forceinline__ void varimax_accum_mfma_pt1(double* __restrict__ sm, 
         __syncthreads();                    // the staging buffers are no longer read
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
-          const int e = tid + 256 * u, j = e / ROT_PB, pt = e % ROT_PB;
+          const int e = tid + 256 * u, j = e / (ROT_PB / 2), pt = 2 * (e % (ROT_PB / 2));
           if (j < p) {
-            const bool ina = pf_in(bt, u);
-            Yr[j * ROT_LDP + pt] = ina ? pfr[d][u] : 0.0;
-            if constexpr (CPLX) Yi[j * ROT_LDP + pt] = ina ? pfi[d][u] : 0.0;
+            const int sa = pf_state(bt, u);
+            Yr[j * ROT_LDP + pt] = pf_first(pfr[d][u], sa);
+            Yr[j * ROT_LDP + pt + 1] = pf_second(pfr[d][u], sa);
+            if constexpr (CPLX) {
+              Yi[j * ROT_LDP + pt] = pf_first(pfi[d][u], sa);
+              Yi[j * ROT_LDP + pt + 1] = pf_second(pfi[d][u], sa);
+            }
             if constexpr (STEP == 2) {
-              const bool inb = pf_in(btb, u);
-              T2r[j * ROT_LDP + pt] = inb ? pfr[d + D2][u] : 0.0;
-              if constexpr (CPLX) T2i[j * ROT_LDP + pt] = inb ? pfi[d + D2][u] : 0.0;
+              const int sb = pf_state(btb, u);
+              T2r[j * ROT_LDP + pt] = pf_first(pfr[d + D2][u], sb);
+              T2r[j * ROT_LDP + pt + 1] = pf_second(pfr[d + D2][u], sb);
+              if constexpr (CPLX) {
+                T2i[j * ROT_LDP + pt] = pf_first(pfi[d + D2][u], sb);
+                T2i[j * ROT_LDP + pt + 1] = pf_second(pfi[d + D2][u], sb);
+              }
             }
           }
         }
@@ -2171,7 +2188,27 @@ __global__ __launch_bounds__(256) void varimax_persistent_kernel(const double* _
             sm[sl * cols + col] = acc;
           }
           __syncthreads();
-          if (tid < cols) {
+          // the slice sums of a column, in slice order.  Many slices (one or two columns per workgroup: grids of 200 and more
+          // workgroups with few modes - the long grids of round 6): first 16 runs of consecutive slices by 16 threads per column, then
+          // the 16 run sums - 256 dependent LDS loads by ONE thread were 16k of the 143k cycles of a C5 iteration.  Up to 64 slices
+          // (C3: 6 columns per workgroup, 42 slices): the plain sequence of rounds 3-5, bit for bit.
+          if (nsl > 64) {
+            const int run = (nsl + 15) / 16;
+            double part = 0.0;
+            const int c2 = tid % cols, r2 = tid / cols;
+            if (r2 < 16) {
+              for (int q = r2 * run; q < min((r2 + 1) * run, nsl); ++q) part += sm[q * cols + c2];
+            }
+            __syncthreads();
+            if (r2 < 16) sm[r2 * cols + c2] = part;
+            __syncthreads();
+            if (tid < cols) {
+              double tot = 0.0;
+              for (int q = 0; q < 16; ++q) tot += sm[q * cols + tid];
+              double* dst = (CPLX && tid >= ne) ? sum_i + e0 + (tid - ne) : sum_r + e0 + tid;
+              __hip_atomic_store(dst, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          } else if (tid < cols) {
             double tot = 0.0;
             for (int q = 0; q < nsl; ++q) tot += sm[q * cols + tid];
             double* dst = (CPLX && tid >= ne) ? sum_i + e0 + (tid - ne) : sum_r + e0 + tid;
